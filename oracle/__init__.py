@@ -1,0 +1,234 @@
+"""CPU oracle for the tape-nonlinearity forward path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+The product (neural-tape-modeling_amd + libntm.so) never does; it fails loudly without its HIP
+library instead of falling back to anything here.
+
+Parity status: pinned by tests/golden/g1..g8 (generated from the reference by
+tools/make_goldens.py); ESR and the TCN are "parity unpinned" (no reference source exists).
+
+Three layers, all restating code/model.py of the reference:
+  * C (ntm_oracle.c via ctypes)  -- fast enough for 16x8192 / 1x65536 cases and the CPU baseline
+  * numpy (np_*)                 -- tiny independent restatement used to cross-check the C
+  * torch_gru_port               -- stock torch.nn.GRU + Linear on CPU, i.e. the very calls the
+                                    reference makes at code/model.py:44-45,81-82 (baseline timing)
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_f64p = ctypes.POINTER(ctypes.c_double)
+_i32p = ctypes.POINTER(ctypes.c_int)
+
+
+def build():
+    """Compile libntm_oracle.so with gcc (idempotent)."""
+    subprocess.run(["make", "-s", "-C", _HERE], check=True)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libntm_oracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = ctypes.CDLL(path)
+        _LIB.ntmo_gru_forward.argtypes = [_f32p] * 6 + [ctypes.c_int, _f32p, _f32p,
+                                                        ctypes.c_int64, ctypes.c_int64, _f32p]
+        _LIB.ntmo_gru_forward_mt.argtypes = _LIB.ntmo_gru_forward.argtypes + [ctypes.c_int]
+        _LIB.ntmo_delay_forward.argtypes = [_f32p, _f32p, _f32p, ctypes.c_int64, ctypes.c_int64,
+                                            _f32p, ctypes.c_int, ctypes.c_int]
+        _LIB.ntmo_esr_sums.argtypes = [_f32p, _f32p, ctypes.c_int64, ctypes.c_int64,
+                                       ctypes.c_int64, _f64p]
+        _LIB.ntmo_tcn_forward.argtypes = [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p,
+                                          _f32p, _f32p, ctypes.c_int64, ctypes.c_int64]
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(_f32p) if a is not None else None
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Weights:
+    """The six GRU-HS parameters in the reference's state_dict layout."""
+
+    def __init__(self, w_ih, w_hh, b_ih, b_hh, w_o, b_o=None):
+        self.w_ih = _c(w_ih).reshape(-1)
+        self.H = self.w_ih.size // 3
+        self.w_hh = _c(w_hh).reshape(3 * self.H, self.H)
+        self.b_ih = _c(b_ih).reshape(-1)
+        self.b_hh = _c(b_hh).reshape(-1)
+        self.w_o = _c(w_o).reshape(-1)
+        self.b_o = None if b_o is None else _c(b_o).reshape(-1)
+
+    @classmethod
+    def from_state_dict(cls, sd):
+        g = lambda k: np.asarray(sd[k], dtype=np.float32) if k in sd else None  # noqa: E731
+        return cls(g("GRU.weight_ih_l0"), g("GRU.weight_hh_l0"), g("GRU.bias_ih_l0"),
+                   g("GRU.bias_hh_l0"), g("output.weight"), g("output.bias"))
+
+
+def gru_forward(w, x, h=None, threads=1):
+    """x [B,T] -> (y [B,T], h_out [B,H]).  code/model.py:81-82."""
+    x = _c(x)
+    B, T = x.shape
+    h = np.zeros((B, w.H), np.float32) if h is None else _c(h).copy()
+    y = np.empty_like(x)
+    args = [_p(w.w_ih), _p(w.w_hh), _p(w.b_ih), _p(w.b_hh), _p(w.w_o), _p(w.b_o), w.H, _p(x), _p(y),
+            B, T, _p(h)]
+    rc = lib().ntmo_gru_forward_mt(*args, threads) if threads > 1 else lib().ntmo_gru_forward(*args)
+    assert rc == 0
+    return y, h
+
+
+def warm_state(w, n=1024):
+    """Hidden state after RNN.warm_start(): 1024 zero samples from h=0 (code/model.py:58-65)."""
+    _, h = gru_forward(w, np.zeros((1, n), np.float32))
+    return h
+
+
+def gru_predict(w, x, threads=1):
+    """Batched generalisation of RNN.predict (code/model.py:218-246): warm state broadcast to all
+    streams, then the whole sequence (the reference's 2048-chunking only carries state)."""
+    x = _c(x)
+    h0 = np.repeat(warm_state(w), x.shape[0], axis=0)
+    return gru_forward(w, x, h0, threads)
+
+
+def delay_forward(x, d, buf, warmup=False):
+    """TimeVaryingDelayLine.forward, code/model.py:269-320.  Returns (y, new_buf); raises
+    AssertionError like the reference (:284) if max(d) > D."""
+    x, d = _c(x), _c(d)
+    buf = _c(buf).copy()
+    B, T = x.shape
+    D = buf.shape[1]
+    y = np.empty_like(x)
+    rc = lib().ntmo_delay_forward(_p(x), _p(d), _p(y), B, T, _p(buf), D, int(bool(warmup)))
+    if rc == 1:
+        raise AssertionError("max_delay >= max(dt) violated")
+    assert rc == 0
+    return y, buf
+
+
+def diffdel_forward(w, x, d, h, buf, warmup=False):
+    """DiffDelRNN.forward, code/model.py:393-424 -> (y, pre_d, h_out, buf_out)."""
+    pre, h = gru_forward(w, x, h)
+    y, buf = delay_forward(pre, d, buf, warmup)
+    return y, pre, h, buf
+
+
+def diffdel_predict(w, x, d, max_delay):
+    """DiffDelRNN.predict, code/model.py:618-653, batched generalisation (same warm state for all
+    streams: zero input, zero delay for 1024 samples)."""
+    x, d = _c(x), _c(d)
+    B = x.shape[0]
+    D = int(max_delay) + 1                                  # code/model.py:372-375
+    z = np.zeros((1, 1024), np.float32)
+    _, _, h1, b1 = diffdel_forward(w, z, z, None, np.zeros((1, D), np.float32))
+    return diffdel_forward(w, x, d, np.repeat(h1, B, 0), np.repeat(b1, B, 0))
+
+
+def esr_sums(y, t, skip=0):
+    y, t = _c(y), _c(t)
+    B, T = y.shape
+    out = np.empty((B, 2), np.float64)
+    assert lib().ntmo_esr_sums(_p(y), _p(t), B, T, skip, out.ctypes.data_as(_f64p)) == 0
+    return out
+
+
+ESR_EPS = 1e-5
+
+
+def esr_per_segment(y, t, skip=0):
+    """CoreAudioML ESRLoss per stream: mean(e^2)/(mean(t^2)+1e-5) over samples [skip,T)."""
+    s = esr_sums(y, t, skip)
+    n = y.shape[1] - skip
+    return (s[:, 0] / n) / (s[:, 1] / n + ESR_EPS)
+
+
+def tcn_forward(params, L, C, K, dil, x):
+    x = _c(x)
+    B, T = x.shape
+    y = np.empty_like(x)
+    params = _c(params)
+    dil = np.ascontiguousarray(dil, dtype=np.int32)
+    assert lib().ntmo_tcn_forward(_p(params), L, C, K, dil.ctypes.data_as(_i32p), _p(x), _p(y), B, T) == 0
+    return y
+
+
+# ----------------------------------------------------------------------------- numpy restatement
+def np_gru_forward(w, x, h=None):
+    """Pure-numpy fp32 restatement (small cases only)."""
+    x = np.asarray(x, np.float32)
+    B, T = x.shape
+    H = w.H
+    h = np.zeros((B, H), np.float32) if h is None else np.asarray(h, np.float32).copy()
+    y = np.empty((B, T), np.float32)
+    sig = lambda v: (np.float32(1) / (np.float32(1) + np.exp(-v))).astype(np.float32)  # noqa: E731
+    for t in range(T):
+        gi = x[:, t:t + 1] * w.w_ih[None, :] + w.b_ih[None, :]
+        gh = h @ w.w_hh.T + w.b_hh[None, :]
+        r = sig(gi[:, :H] + gh[:, :H])
+        z = sig(gi[:, H:2 * H] + gh[:, H:2 * H])
+        n = np.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:]).astype(np.float32)
+        h = ((h - n) * z + n).astype(np.float32)
+        y[:, t] = h @ w.w_o + (w.b_o[0] if w.b_o is not None else np.float32(0))
+    return y, h
+
+
+def np_delay_forward(x, d, buf, warmup=False):
+    """The reference's own O(T*D) formulation (code/model.py:287-315) in numpy, for tiny cases."""
+    x, d, buf = (np.asarray(a, np.float32) for a in (x, d, buf))
+    B, T = x.shape
+    D = buf.shape[1]
+    assert D >= d.max()
+    xp = np.concatenate([buf, x], axis=1)
+    nb = np.concatenate([buf[:, T:], x[:, -D:] if D > 0 else x[:, :0]], axis=1)
+    if warmup:
+        return x.copy(), nb
+    unf = np.lib.stride_tricks.sliding_window_view(xp, D + 1, axis=1)        # [B,T,D+1]
+    dist = np.linspace(D, 0, D + 1, dtype=np.float32)
+    wts = np.maximum(np.float32(1) - np.abs(dist[None, None, :] - d[:, :, None]), np.float32(0))
+    y = (wts * unf).astype(np.float32).sum(axis=2, dtype=np.float32)
+    return y, nb
+
+
+# ----------------------------------------------------------------------------- torch CPU port
+def torch_gru_port(w):
+    """torch.nn.GRU(1,H,batch_first=True)+Linear(H,1) loaded with `w`: exactly the modules the
+    reference builds at code/model.py:44-45 (and :364-365), on CPU.  Returns f(x[B,T], h0[B,H]) ->
+    (y, h)."""
+    import torch
+
+    gru = torch.nn.GRU(1, w.H, batch_first=True)
+    lin = torch.nn.Linear(w.H, 1, bias=w.b_o is not None)
+    with torch.no_grad():
+        gru.weight_ih_l0.copy_(torch.from_numpy(w.w_ih).view(3 * w.H, 1))
+        gru.weight_hh_l0.copy_(torch.from_numpy(w.w_hh))
+        gru.bias_ih_l0.copy_(torch.from_numpy(w.b_ih))
+        gru.bias_hh_l0.copy_(torch.from_numpy(w.b_hh))
+        lin.weight.copy_(torch.from_numpy(w.w_o).view(1, w.H))
+        if w.b_o is not None:
+            lin.bias.copy_(torch.from_numpy(w.b_o))
+    gru.eval()
+    lin.eval()
+
+    def f(x, h0=None):
+        with torch.inference_mode():
+            xt = torch.as_tensor(x, dtype=torch.float32)
+            B, T = xt.shape
+            h = None if h0 is None else torch.as_tensor(h0, dtype=torch.float32).view(1, B, w.H)
+            o, hn = gru(xt.reshape(B, T, 1), h)
+            return lin(o).reshape(B, T).numpy(), hn.view(B, w.H).numpy()
+
+    return f

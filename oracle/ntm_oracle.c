@@ -1,0 +1,208 @@
+/*
+ * ntm_oracle.c -- CPU restatement of the reference's tape-nonlinearity forward path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it.  The product path (libntm.so, HIP) never calls it.
+ *
+ * Parity status: PINNED by golden vectors generated in the build container by importing the
+ * reference itself (tools/make_goldens.py -> tests/golden/g1..g8); the reference ships no tests
+ * of its own.  tests/test_oracle.py checks every function below against them.
+ *
+ * What is restated (file:line relative to the reference checkout):
+ *   ntmo_gru_forward     code/model.py:67-88 (RNN.forward) and :393-415 (DiffDelRNN.forward, GRU part)
+ *                        = torch.nn.GRU(1,H,batch_first=True) + torch.nn.Linear(H,1[,bias=False]),
+ *                        a third-party dependency (PyTorch, unpinned in environment.yaml:7-8).  The
+ *                        published GRU equations, gate row order (r,z,n), in the operation order of
+ *                        ATen's CPU cell:  r=s(gi_r+gh_r) z=s(gi_z+gh_z) n=tanh(gi_n+r*gh_n)
+ *                        h'=(h-n)*z+n ;  y=W_o.h'(+b_o)
+ *   ntmo_delay_forward   code/model.py:269-320 (TimeVaryingDelayLine.forward) in closed form: of the
+ *                        D+1 interpolation weights relu(1-|m-d|) at most the taps m=floor(d), floor(d)+1
+ *                        are non-zero; every fp32 operation is kept in the reference's order so the
+ *                        result is bit-identical (compile with -ffp-contract=off).
+ *   ntmo_esr_sums        the un-vendored CoreAudioML ESRLoss used at code/test-model.py:250-254:
+ *                        mean((t-y)^2)/(mean(t^2)+1e-5); this returns the two sums per stream.
+ *                        PARITY UNPINNED for this one (source absent from the reference tree).
+ *   ntmo_tcn_forward     builder-defined causal dilated Conv1d stack (no reference implementation
+ *                        exists: code/micro_tcn is an empty submodule).  PARITY UNPINNED; checked
+ *                        against torch.nn.functional.conv1d in tests.
+ *
+ * All arrays are dense row-major fp32.  Streams are independent; "_mt" variants split streams over
+ * OpenMP threads (used only for the cpu_baseline timing).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+/* one stream: x[T] -> y[T], h[H] in/out */
+static void gru_stream(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                       const float *w_o, const float *b_o, int H, const float *x, float *y,
+                       int64_t T, float *h)
+{
+    float *gh = (float *)malloc(sizeof(float) * 3 * (size_t)H);
+    float *hn = (float *)malloc(sizeof(float) * (size_t)H);
+    for (int64_t t = 0; t < T; ++t) {
+        const float xt = x[t];
+        for (int g = 0; g < 3 * H; ++g) {
+            const float *row = w_hh + (size_t)g * H;
+            float acc = 0.0f;
+            for (int k = 0; k < H; ++k) acc += row[k] * h[k];
+            gh[g] = acc + b_hh[g];
+        }
+        float yo = 0.0f;
+        for (int j = 0; j < H; ++j) {
+            const float gi_r = w_ih[j] * xt + b_ih[j];
+            const float gi_z = w_ih[H + j] * xt + b_ih[H + j];
+            const float gi_n = w_ih[2 * H + j] * xt + b_ih[2 * H + j];
+            const float r = sigmoidf_(gi_r + gh[j]);
+            const float z = sigmoidf_(gi_z + gh[H + j]);
+            const float n = tanhf(gi_n + r * gh[2 * H + j]);
+            hn[j] = (h[j] - n) * z + n;
+            yo += w_o[j] * hn[j];
+        }
+        memcpy(h, hn, sizeof(float) * (size_t)H);
+        y[t] = b_o ? yo + b_o[0] : yo;
+    }
+    free(gh);
+    free(hn);
+}
+
+/* code/model.py:81-82.  h_state [B,H] in/out (caller passes zeros for hidden=None). */
+int ntmo_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                     const float *w_o, const float *b_o, int H, const float *x, float *y,
+                     int64_t B, int64_t T, float *h_state)
+{
+    if (H <= 0 || B < 0 || T < 0) return -1;
+    for (int64_t b = 0; b < B; ++b)
+        gru_stream(w_ih, w_hh, b_ih, b_hh, w_o, b_o, H, x + b * T, y + b * T, T, h_state + b * H);
+    return 0;
+}
+
+int ntmo_gru_forward_mt(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                        const float *w_o, const float *b_o, int H, const float *x, float *y,
+                        int64_t B, int64_t T, float *h_state, int threads)
+{
+    if (H <= 0 || B < 0 || T < 0) return -1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (int64_t b = 0; b < B; ++b)
+        gru_stream(w_ih, w_hh, b_ih, b_hh, w_o, b_o, H, x + b * T, y + b * T, T, h_state + b * H);
+    return 0;
+}
+
+/*
+ * code/model.py:269-320.  x,d,y [B,T]; dl_state [B,D] = the reference's `buffer` (oldest first).
+ * Returns 0, or 1 if max(d) > D (the reference's `assert self.max_delay >= torch.max(dt)`, :284;
+ * nothing is written in that case).  y may not alias x.
+ */
+int ntmo_delay_forward(const float *x, const float *d, float *y, int64_t B, int64_t T,
+                       float *dl_state, int D, int warmup)
+{
+    if (D < 0 || B < 0 || T < 0) return -1;
+    for (int64_t i = 0; i < B * T; ++i)
+        if (d[i] > (float)D) return 1;
+    float *nb = (float *)malloc(sizeof(float) * (size_t)(D > 0 ? D : 1));
+    for (int64_t b = 0; b < B; ++b) {
+        const float *xb = x + b * T, *db = d + b * T;
+        float *yb = y + b * T, *buf = dl_state + b * (int64_t)D;
+        if (warmup) {
+            if (yb != xb) memcpy(yb, xb, sizeof(float) * (size_t)T);     /* :288-292 returns x */
+        } else {
+            for (int64_t n = 0; n < T; ++n) {
+                const float dn = db[n];
+                const int64_t k = (int64_t)floorf(dn);
+                float acc = 0.0f;
+                /* j ascending in the reference <=> tap delay m descending: m=k+1 first, then m=k */
+                for (int64_t m = k + 1; m >= k; --m) {
+                    if (m < 0 || m > D) continue;
+                    float w = 1.0f - fabsf((float)m - dn);
+                    if (!(w > 0.0f)) continue;
+                    const int64_t src = n - m;
+                    const float xv = src >= 0 ? xb[src] : buf[D + src];
+                    acc = acc + w * xv;
+                }
+                yb[n] = acc;
+            }
+        }
+        /* buffer = cat(buffer[T:], x[-D:])   (:314-315) */
+        if (T >= D) {
+            memcpy(nb, xb + (T - D), sizeof(float) * (size_t)D);
+        } else {
+            memcpy(nb, buf + T, sizeof(float) * (size_t)(D - T));
+            memcpy(nb + (D - T), xb, sizeof(float) * (size_t)T);
+        }
+        memcpy(buf, nb, sizeof(float) * (size_t)D);
+    }
+    free(nb);
+    return 0;
+}
+
+/* per-stream sums over samples [skip,T): out[b*2+0]=sum (t-y)^2, out[b*2+1]=sum t^2 (fp64) */
+int ntmo_esr_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, double *out)
+{
+    if (skip < 0 || skip > T) return -1;
+    for (int64_t b = 0; b < B; ++b) {
+        double se = 0.0, st = 0.0;
+        for (int64_t n = skip; n < T; ++n) {
+            const float e = t[b * T + n] - y[b * T + n];
+            se += (double)e * (double)e;
+            st += (double)t[b * T + n] * (double)t[b * T + n];
+        }
+        out[b * 2 + 0] = se;
+        out[b * 2 + 1] = st;
+    }
+    return 0;
+}
+
+/*
+ * Builder-defined TCN (DESIGN.md "K4"): L causal blocks; block i:
+ *   u = causal_dilated_conv1d(in, W_i[C_out,C_in,K], b_i, dilation dil[i])   (zero history)
+ *   v = PReLU(u, a_i[C_out])
+ *   out = v + (res_w_i ? conv1x1(in, res_w_i[C_out,C_in]) : in)
+ * followed by a 1x1 output conv (C->1, bias).  x [B,T] (C_in of block 0 is 1), y [B,T].
+ * Parameters are packed block after block: W, b, a, res_w (always present), then out_w[C], out_b[1].
+ */
+int ntmo_tcn_forward(const float *params, int L, int C, int K, const int *dil, const float *x,
+                     float *y, int64_t B, int64_t T)
+{
+    if (L <= 0 || C <= 0 || K <= 0) return -1;
+    float *a = (float *)malloc(sizeof(float) * (size_t)C * (size_t)T);
+    float *c = (float *)malloc(sizeof(float) * (size_t)C * (size_t)T);
+    for (int64_t b = 0; b < B; ++b) {
+        int cin = 1;
+        const float *p = params;
+        memcpy(a, x + b * T, sizeof(float) * (size_t)T);
+        for (int l = 0; l < L; ++l) {
+            const float *W = p;            p += (size_t)C * cin * K;
+            const float *bias = p;         p += C;
+            const float *alpha = p;        p += C;
+            const float *rw = p;           p += (size_t)C * cin;
+            for (int co = 0; co < C; ++co) {
+                for (int64_t n = 0; n < T; ++n) {
+                    float u = bias[co];
+                    for (int ci = 0; ci < cin; ++ci)
+                        for (int k = 0; k < K; ++k) {
+                            const int64_t src = n - (int64_t)(K - 1 - k) * dil[l];
+                            if (src >= 0) u += W[((size_t)co * cin + ci) * K + k] * a[(size_t)ci * T + src];
+                        }
+                    const float v = u >= 0.0f ? u : alpha[co] * u;
+                    float r = 0.0f;
+                    for (int ci = 0; ci < cin; ++ci) r += rw[(size_t)co * cin + ci] * a[(size_t)ci * T + n];
+                    c[(size_t)co * T + n] = v + r;
+                }
+            }
+            float *tmp = a; a = c; c = tmp;
+            cin = C;
+        }
+        const float *ow = p, *ob = p + C;
+        for (int64_t n = 0; n < T; ++n) {
+            float acc = ob[0];
+            for (int ci = 0; ci < C; ++ci) acc += ow[ci] * a[(size_t)ci * T + n];
+            y[b * T + n] = acc;
+        }
+    }
+    free(a);
+    free(c);
+    return 0;
+}

@@ -1,0 +1,135 @@
+"""CPU: pin the oracle (C + numpy restatements) against goldens generated from the reference.
+
+Tolerances: GRU path 2e-6 abs (reference-vs-reference batched/single already differs by 3.4e-7,
+SURVEY.md §8(c)); delay line bit-exact.
+"""
+import numpy as np
+import pytest
+
+import oracle
+from helpers import load, oracle_weights
+
+GRU_TOL = 2e-6
+
+
+def test_g1_predict_real_material():
+    g = load("g1_predict_16x8192.npz")
+    w = oracle_weights(g["weights"])
+    y, _ = oracle.gru_predict(w, g["x"], threads=4)
+    assert np.abs(y - g["y"]).max() < GRU_TOL
+
+
+def test_g2_forward_batched_state_carry_and_f64_cast():
+    g = load("g2_forward_carry.npz")
+    w = oracle_weights(g["weights"])
+    x = g["x"][:, 0, :]
+    y0, h = oracle.gru_forward(w, x[:, :1500])
+    y1, h = oracle.gru_forward(w, x[:, 1500:], h)
+    assert np.abs(np.concatenate([y0, y1], 1) - g["y"][:, 0, :]).max() < GRU_TOL
+    assert np.abs(h - g["hidden"][0]).max() < GRU_TOL
+    y64, _ = oracle.gru_forward(w, g["x"][:2, 0, :256].astype(np.float64))
+    assert np.abs(y64 - g["y64"][:, 0, :]).max() < GRU_TOL
+
+
+def test_g3_warm_start_state():
+    g = load("g3_warm_start.npz")
+    names = {"wg": "GRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE]_BEST",
+             "wg_esr": "GRU-HS[64]-L[ESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE]_BEST",
+             "wd": "DiffDelGRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE_WOWFLUTTER]_BEST",
+             "wd_esr": "DiffDelGRU-HS[64]-L[ESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE_WOWFLUTTER]_BEST"}
+    for tag, name in names.items():
+        w = oracle_weights(name)
+        assert np.abs(oracle.warm_state(w) - g[f"{tag}_hidden"][0]).max() < GRU_TOL
+        if tag.startswith("wd"):
+            z = np.zeros((1, 1024), np.float32)
+            D = g[f"{tag}_buffer"].shape[2]
+            _, _, _, buf = oracle.diffdel_forward(w, z, z, None, np.zeros((1, D), np.float32))
+            assert np.abs(buf - g[f"{tag}_buffer"][:, 0, :]).max() < GRU_TOL
+
+
+@pytest.mark.parametrize("impl", ["c", "numpy"])
+def test_g4_delay_line_bit_exact(impl):
+    g = load("g4_delay_line.npz")
+    fwd = oracle.delay_forward if impl == "c" else oracle.np_delay_forward
+    D = int(g["D"])
+    x, d = g["x"][:, 0, :], g["d"][:, 0, :]
+    buf = np.zeros((3, D), np.float32)
+    bounds = g["bounds"]
+    for i, (a, b) in enumerate(zip(bounds[:-1], bounds[1:])):
+        y, buf = fwd(x[:, a:b], d[:, a:b], buf)
+        assert np.array_equal(y, g["y"][:, 0, a:b]), f"chunk {i}"
+        assert np.array_equal(buf, g["buf_after_each"][i][:, 0, :]), f"buffer {i}"
+    yw, bw = fwd(x[:, :50], d[:, :50], np.zeros((3, D), np.float32), warmup=True)
+    assert np.array_equal(yw, g["y_warm"][:, 0, :]) and np.array_equal(bw, g["buf_warm"][:, 0, :])
+    y2, _ = fwd(x[:, 50:100], d[:, 50:100], bw)
+    assert np.array_equal(y2, g["y_after_warm"][:, 0, :])
+
+
+def test_delay_assertion_like_reference():
+    x = np.zeros((1, 8), np.float32)
+    d = np.full((1, 8), 5.5, np.float32)
+    with pytest.raises(AssertionError):
+        oracle.delay_forward(x, d, np.zeros((1, 5), np.float32))
+
+
+def test_g5_diffdel_predict():
+    g = load("g5_diffdel_predict.npz")
+    w = oracle_weights(g["weights"])
+    assert w.b_o is None
+    y, pre, h, buf = oracle.diffdel_predict(w, g["x"][:, 0, :], g["d"][:, 0, :], int(g["max_delay"]))
+    assert buf.shape[1] == int(g["D_effective"]) == int(g["max_delay"]) + 1
+    assert np.abs(pre - g["pre_d"][:, 0, :]).max() < GRU_TOL
+    assert np.abs(y - g["y"][:, 0, :]).max() < GRU_TOL
+    assert np.abs(buf - g["buffer"][:, 0, :]).max() < GRU_TOL
+    assert np.abs(h - g["hidden"][0]).max() < GRU_TOL
+
+
+def test_g6_long_sequence_no_drift():
+    g = load("g6_long_65536.npz")
+    w = oracle_weights(g["weights"])
+    y, _ = oracle.gru_predict(w, g["x"][:, 0, :])
+    err = np.abs(y - g["y"][:, 0, :])
+    assert err.max() < GRU_TOL
+    assert err[0, -8192:].max() < 2 * max(err[0, :8192].max(), 5e-7)
+
+
+def test_g8_diffdel_batched_validate_style():
+    g = load("g8_diffdel_batched.npz")
+    w = oracle_weights(g["weights"])
+    x, d = g["x"][:, 0, :], g["d"][:, 0, :]
+    B, T = x.shape
+    init, chunk, D = int(g["init_len"]), int(g["chunk"]), int(g["max_delay"]) + 1
+    h, buf = None, np.zeros((B, D), np.float32)
+    ys, ps = [], []
+    y, p, h, buf = oracle.diffdel_forward(w, x[:, :init], d[:, :init], h, buf, warmup=True)
+    ys.append(y); ps.append(p)
+    for off in range(init, T, chunk):
+        y, p, h, buf = oracle.diffdel_forward(w, x[:, off:off + chunk], d[:, off:off + chunk], h, buf)
+        ys.append(y); ps.append(p)
+    assert np.abs(np.concatenate(ys, 1) - g["y"][:, 0, :]).max() < GRU_TOL
+    assert np.abs(np.concatenate(ps, 1) - g["pre_d"][:, 0, :]).max() < GRU_TOL
+    assert np.abs(buf - g["buffer"][:, 0, :]).max() < GRU_TOL
+    assert np.abs(h - g["hidden"][0]).max() < GRU_TOL
+
+
+def test_numpy_and_torch_port_agree_with_c():
+    w = oracle_weights("GRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE]_BEST")
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-0.5, 0.5, (3, 300)).astype(np.float32)
+    yc, hc = oracle.gru_forward(w, x)
+    yn, hn = oracle.np_gru_forward(w, x)
+    yt, ht = oracle.torch_gru_port(w)(x)
+    assert np.abs(yc - yn).max() < GRU_TOL and np.abs(hc - hn).max() < GRU_TOL
+    assert np.abs(yc - yt).max() < GRU_TOL and np.abs(hc - ht).max() < GRU_TOL
+    ym, hm = oracle.gru_forward(w, x, threads=3)
+    assert np.array_equal(ym, yc) and np.array_equal(hm, hc)
+
+
+def test_esr_definition():
+    rng = np.random.default_rng(5)
+    t = rng.standard_normal((4, 1000)).astype(np.float32)
+    y = t + 0.1 * rng.standard_normal((4, 1000)).astype(np.float32)
+    e = oracle.esr_per_segment(y, t, skip=100)
+    t64, y64 = t[:, 100:].astype(np.float64), y[:, 100:].astype(np.float64)
+    want = np.mean((t64 - y64) ** 2, 1) / (np.mean(t64 ** 2, 1) + 1e-5)
+    assert np.allclose(e, want, rtol=1e-6)
