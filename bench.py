@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio samples/s through GRU-HS[64] (CHOWTAPE weights), batch 4096 segments
+x 65 536 samples fp32 per GPU (BASELINE.json configs[1]); weak scaling over N GPUs (configs[4]:
+N x 4096 segments, sharded by stream, one RCCL all-reduce of the ESR scalars).
+
+A "step" = one pass of the hot path over the rank's batch, inputs resident in HBM:
+    warm-start (1024 zero samples, B=1) -> persistent GRU kernel over [B,T] -> per-stream ESR sums
+    against a resident target -> all-reduce of 4 fp64 scalars.
+The target is the output of the first (untimed) pass, so the ESR of every timed pass must be
+exactly 0.0 -- a full-size determinism check -- and stream 0 carries the input of golden G6 so the
+result is also checked against the REFERENCE's own output on 65 536 samples.
+
+    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FS = 44100
+FLOP_PER_SAMPLE = 25088          # 12 544 FMA: W_hh GEMV 12 288 + W_ih 192 + head 64
+BYTES_PER_SAMPLE = 8             # 4 B x in + 4 B y out
+PEAK_FP32_TFLOPS = 157.3         # MI355X fp32 matrix == vector peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def synth_input(B, T, device, seed):
+    """per-stream sinusoid (log-uniform 40 Hz-8 kHz) x 1-Hz raised-cosine
+    envelope in [0.1,1] + 0.05 N(0,1); generated on the device."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    f = 40.0 * (8000.0 / 40.0) ** torch.rand(B, 1, generator=g, device=device)
+    ph = 2 * np.pi * torch.rand(B, 1, generator=g, device=device)
+    pe = 2 * np.pi * torch.rand(B, 1, generator=g, device=device)
+    x = torch.empty(B, T, device=device)
+    n = torch.arange(T, device=device, dtype=torch.float32).unsqueeze(0)
+    CH = 256
+    for b0 in range(0, B, CH):
+        sl = slice(b0, min(B, b0 + CH))
+        env = 0.55 - 0.45 * torch.cos(2 * np.pi * 1.0 * n / FS + pe[sl])
+        x[sl] = 0.5 * torch.sin(2 * np.pi * f[sl] * n / FS + ph[sl]) * env
+        x[sl] += 0.05 * torch.randn(x[sl].shape, generator=g, device=device)
+    return x.unsqueeze(1)
+
+
+def cpu_baseline(w_name, seconds_budget=25.0):
+    """Reference CPU path timed on this host: stock torch.nn.GRU + Linear on CPU (the modules the
+    reference builds at code/model.py:44-45) on a bounded sample of the workload, all cores; the C
+    oracle (OpenMP over streams) beside it."""
+    import oracle
+    from ntm_amd import weights
+    sd = weights.load_state_dict(w_name)
+    w = oracle.Weights.from_state_dict({k: v.numpy() for k, v in sd.items()})
+    rng = np.random.default_rng(0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    f = oracle.torch_gru_port(w)
+    h0 = np.repeat(oracle.warm_state(w), 64, 0)
+    best, sample = 0.0, ""
+    t_used = 0.0
+    for B, T in [(16, 8192), (64, 8192)]:
+        x = rng.uniform(-0.5, 0.5, (B, T)).astype(np.float32)
+        f(x[:, :256], h0[:B])                                    # thread-pool warm-up
+        t0 = time.perf_counter()
+        f(x, h0[:B])
+        dt = time.perf_counter() - t0
+        t_used += dt
+        if B * T / dt > best:
+            best, sample = B * T / dt, f"{B}x{T} samples, torch.nn.GRU+Linear CPU, {torch.get_num_threads()} threads"
+        if t_used > seconds_budget:
+            break
+    x = rng.uniform(-0.5, 0.5, (4 * cores, 8192)).astype(np.float32)
+    t0 = time.perf_counter()
+    oracle.gru_forward(w, x, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": best, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port", "sample": sample,
+            "oracle_c": {"value": x.size / dt, "unit": "samples/s", "cores": cores,
+                         "sample": f"{x.shape[0]}x8192 samples, C restatement, OpenMP over streams"}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=4096, help="segments per GPU")
+    ap.add_argument("--samples", type=int, default=65536, help="samples per segment")
+    ap.add_argument("--variant", default="auto", choices=["auto", "mfma", "valu"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import ntm_amd
+    from ntm_amd import distributed as D, weights
+    from ntm_amd.model import esr_sums, ESR_EPS
+
+    rank, world, local = D.init_from_env("nccl")
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs the MI355X"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    B, T = a.batch, a.samples
+
+    model = ntm_amd.harness.build_model(weights.W_GRU, device=dev)
+    model.kernel_variant = a.variant
+    x = synth_input(B, T, dev, seed=1234 + rank)
+    gold = None
+    if rank == 0 and T == 65536:
+        gold = np.load(os.path.join(ROOT, "tests", "golden", "g6_long_65536.npz"))
+        x[0, 0] = torch.from_numpy(gold["x"][0, 0]).to(dev)
+    INIT_LEN = 1024
+
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    kern_ms = []
+
+    def one_pass(target):
+        # == model.predict(x) (code/model.py:218-246), unrolled so the events bracket the main launch
+        model.initialize_hidden()
+        model.warm_start()
+        model.hidden = model.hidden.expand(1, B, 64).contiguous()
+        ev0.record()
+        y = model.forward(x)
+        ev1.record()
+        res = None
+        if target is not None:
+            s = esr_sums(y, target, skip=INIT_LEN)
+            n = T - INIT_LEN
+            res = D.reduce_loss_sums((s[:, 0] / n) / (s[:, 1] / n + ESR_EPS), s)
+        return y, res
+
+    target = None
+    for _ in range(max(a.warmup, 0)):
+        y, _ = one_pass(target)
+        if target is None:
+            target = y.clone()
+    if target is None:                      # --warmup 0: still need the determinism target
+        target = one_pass(None)[0].clone()
+
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = None
+    for _ in range(a.steps):
+        y, res = one_pass(target)
+        torch.cuda.synchronize()
+        kern_ms.append(ev0.elapsed_time(ev1))
+    torch.cuda.synchronize()
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+
+    if rank != 0:
+        return
+    total_samples = float(B) * T * world * a.steps
+    kern_s = float(np.mean(kern_ms)) / 1e3
+    tflops = FLOP_PER_SAMPLE * B * T / kern_s / 1e12
+    hbm_gbs = BYTES_PER_SAMPLE * B * T / kern_s / 1e9
+    checks = {"esr_vs_first_pass": res["ESR"] if res else None, "segments": res["segments"] if res else None}
+    if gold is not None:
+        yg = y[0, 0].cpu().numpy()
+        e = gold["y"][0, 0] - yg
+        checks["stream0_vs_reference_max_abs"] = float(np.abs(e).max())
+        checks["stream0_vs_reference_esr"] = float((e[INIT_LEN:] ** 2).mean() /
+                                                   ((gold["y"][0, 0][INIT_LEN:] ** 2).mean() + ESR_EPS))
+    out = {
+        "metric": "audio samples/sec (44.1 kHz) GRU-HS[64], batch=4096x65536",
+        "value": total_samples / elapsed, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"GRU-HS[64] CHOWTAPE weights, {B} segments x {T} samples fp32 per GPU, "
+                               f"predict (warm-start + persistent GRU kernel) + ESR sums + all-reduce",
+                   "segments_per_gpu": B, "samples_per_segment": T, "kernel": a.variant,
+                   "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
+        "realtime_factor": total_samples / elapsed / FS,
+        "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                     "frac": tflops / PEAK_FP32_TFLOPS, "traffic": None,
+                     "kernel": "gru_mfma_kernel" if a.variant != "valu" else "gru_valu_kernel",
+                     "kernel_ms": 1e3 * kern_s, "flop_per_sample": FLOP_PER_SAMPLE,
+                     "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": hbm_gbs / PEAK_HBM_GBS, "bytes_per_sample": BYTES_PER_SAMPLE}},
+        "checks": checks,
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(weights.W_GRU)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

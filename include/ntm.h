@@ -1,0 +1,120 @@
+/*
+ * ntm.h -- C ABI of libntm.so: the MI355X (gfx950) kernels for the neural tape-nonlinearity
+ * forward path of 01tot10/neural-tape-modeling.
+ *
+ * The reference has no FFI for this path: it is a Python torch.nn.Module protocol
+ * (code/model.py).  Each entry point below names the reference call it replaces; the Python
+ * host layer (neural-tape-modeling_amd/model.py) rebuilds the reference's object protocol on top
+ * of these and INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller (fp32 unless noted); nothing is
+ *     allocated or freed inside; no global state (carried state lives in the caller's h_state /
+ *     dl_state buffers), so calls are re-entrant;
+ *   - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL = default);
+ *   - audio tensors are [B, T] row-major views of the reference's (B,1,T) layout with explicit
+ *     per-stream strides in ELEMENTS (>= T);
+ *   - return value: 0 on success, negative NTM_E* on failure; ntm_last_error() gives the
+ *     thread-local message.  There is NO CPU fallback: without a HIP device every call fails.
+ */
+#ifndef NTM_H
+#define NTM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NTM_OK 0
+#define NTM_EINVAL (-1)  /* bad argument (null pointer, negative size, unsupported H)  */
+#define NTM_EHIP (-2)    /* HIP runtime error (launch failed, no device)               */
+#define NTM_EDELAY (-3)  /* reserved for host-side delay-range checks                  */
+
+#define NTM_HIDDEN 64 /* the only hidden size compiled (every shipped checkpoint is HS[64]) */
+
+/* GRU kernel variants for ntm_gru_forward_ex:                              */
+#define NTM_GRU_AUTO 0  /* pick by B                                                        */
+#define NTM_GRU_MFMA 1  /* 16 streams / workgroup, 4 waves, v_mfma_f32_16x16x4_f32, h in LDS */
+#define NTM_GRU_VALU 2  /* 2 streams / wavefront, W_hh in VGPRs, h broadcast through LDS     */
+
+/* ABI version of this header; bumped on any signature change. */
+int ntm_abi_version(void);
+
+/* Thread-local message for the last failing call on this thread ("" if none). */
+const char *ntm_last_error(void);
+
+/*
+ * Replaces  x, self.hidden = self.GRU(x, self.hidden); y = self.output(x)
+ * at code/model.py:81-82 (RNN.forward) and :412-413 (DiffDelRNN.forward, where b_o == NULL
+ * because the head is Linear(..., bias=False), code/model.py:365).
+ *
+ * Weights in the reference's state_dict layout, gate row order r,z,n:
+ *   w_ih [3H]      GRU.weight_ih_l0 (3H,1)      w_hh [3H,H]   GRU.weight_hh_l0
+ *   b_ih [3H]      GRU.bias_ih_l0               b_hh [3H]     GRU.bias_hh_l0
+ *   w_o  [H]       output.weight (1,H)          b_o  [1] or NULL   output.bias
+ * x [B,T] (stride x_stride_b) -> y [B,T] (stride y_stride_b).
+ * h_state [B,H] is read as h_0 and overwritten with h_T (the reference's self.hidden);
+ * NULL means h_0 = 0 and h_T is discarded.  B == 0 or T == 0 is a successful no-op.
+ */
+int ntm_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                    const float *w_o, const float *b_o, int H, const float *x, float *y,
+                    int64_t B, int64_t T, int64_t x_stride_b, int64_t y_stride_b, float *h_state,
+                    void *stream);
+
+/* Same, with an explicit kernel variant (NTM_GRU_*); used by bench.py / tests to A/B kernels. */
+int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                       const float *w_o, const float *b_o, int H, const float *x, float *y,
+                       int64_t B, int64_t T, int64_t x_stride_b, int64_t y_stride_b,
+                       float *h_state, int variant, void *stream);
+
+/*
+ * Replaces TimeVaryingDelayLine.forward(x, dt, warmup), code/model.py:269-320.
+ * x, d, y: [B,T] contiguous (stride T); d in SAMPLES.  dl_state [B,D] is the reference's
+ * `self.buffer` (oldest sample first) and is updated in place to cat(buffer[T:], x[-D:]).
+ * warmup != 0: y = x, only the buffer is updated (code/model.py:288-292).
+ * y must not alias x.  `scratch` must hold B*min(T,D)... see ntm_delay_scratch_floats().
+ * err_flag (device int32, may be NULL): set to 1 if any d > D -- the reference raises
+ * AssertionError there (code/model.py:284); the caller checks it after synchronising.
+ */
+int ntm_delay_forward(const float *x, const float *d, float *y, int64_t B, int64_t T,
+                      float *dl_state, int D, int warmup, float *scratch, int32_t *err_flag,
+                      void *stream);
+
+/* Number of floats ntm_delay_forward needs in `scratch` for (B,T,D). */
+int64_t ntm_delay_scratch_floats(int64_t B, int64_t T, int D);
+
+/*
+ * Replaces DiffDelRNN.forward(x, del_traj, warmup), code/model.py:393-424:
+ * the GRU + bias-free head writes pre_d, then the delay line writes y.  Returns (y, pre_d)
+ * through the two output pointers; h_state and dl_state as above.
+ */
+int ntm_diffdel_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih,
+                            const float *b_hh, const float *w_o, int H, const float *x,
+                            const float *d, float *y, float *pre_d, int64_t B, int64_t T,
+                            float *h_state, float *dl_state, int D, int warmup, float *scratch,
+                            int32_t *err_flag, void *stream);
+
+/*
+ * Per-stream sums for the ESR loss that follows the path in code/test-model.py:250-254,386-388
+ * (CoreAudioML ESRLoss, un-vendored): over samples [skip, T) of stream b
+ *   out[2b] = sum (t - y)^2      out[2b+1] = sum t^2        (fp64, device)
+ * y, t: [B,T] contiguous.
+ */
+int ntm_esr_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, double *out,
+                 void *stream);
+
+/*
+ * Builder-defined causal dilated-Conv1d TCN (BASELINE.json config 4; the reference has no TCN:
+ * code/micro_tcn is an empty submodule).  Spec and parameter packing: DESIGN.md "K4" and
+ * oracle/ntm_oracle.c:ntmo_tcn_forward.  x,y [B,T] contiguous; dil[L] host array; `scratch`
+ * holds ntm_tcn_scratch_floats(B,T,C) floats.
+ */
+int ntm_tcn_forward(const float *params, int L, int C, int K, const int *dil, const float *x,
+                    float *y, int64_t B, int64_t T, float *scratch, void *stream);
+int64_t ntm_tcn_scratch_floats(int64_t B, int64_t T, int C);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NTM_H */

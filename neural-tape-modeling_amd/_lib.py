@@ -1,0 +1,73 @@
+"""ctypes binding of libntm.so (the C ABI in include/ntm.h).
+
+There is deliberately no fallback of any kind: if the HIP library is missing or no HIP device is
+present, calls raise.  Nothing here imports or calls oracle/.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libntm.so")
+
+NTM_GRU_AUTO, NTM_GRU_MFMA, NTM_GRU_VALU = 0, 1, 2
+VARIANTS = {"auto": NTM_GRU_AUTO, "mfma": NTM_GRU_MFMA, "valu": NTM_GRU_VALU}
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+
+_SIGNATURES = {
+    "ntm_abi_version": (_int, []),
+    "ntm_last_error": (ctypes.c_char_p, []),
+    "ntm_gru_forward": (_int, [_vp] * 6 + [_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "ntm_gru_forward_ex": (_int, [_vp] * 6 + [_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp]),
+    "ntm_delay_forward": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _int, _int, _vp, _vp, _vp]),
+    "ntm_delay_scratch_floats": (_i64, [_i64, _i64, _int]),
+    "ntm_diffdel_gru_forward": (_int, [_vp] * 5 + [_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _int,
+                                                   _vp, _vp, _vp]),
+    "ntm_esr_sums": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "ntm_tcn_forward": (_int, [_vp, _int, _int, _int, ctypes.POINTER(_int), _vp, _vp, _i64, _i64, _vp, _vp]),
+    "ntm_tcn_scratch_floats": (_i64, [_i64, _i64, _int]),
+}
+
+_lib = None
+
+
+class NtmError(RuntimeError):
+    """A libntm.so entry point returned a negative status."""
+
+
+def build(verbose=False):
+    """Compile libntm.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    subprocess.run(["make", "-C", os.path.join(_HERE, "csrc")] + ([] if verbose else ["-s"]), check=True)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NtmError(f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                           "(there is no CPU fallback for this path)")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise NtmError(f"{what} failed ({rc}): {lib().ntm_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,121 @@
+// extern "C" surface of libntm.so (declared in include/ntm.h): argument checking, variant choice,
+// error reporting.  No allocation, no synchronisation, no global mutable state besides the
+// thread-local error string.
+#include "ntm.h"
+#include "ntm_common.h"
+
+#include <string>
+
+namespace ntm {
+hipError_t launch_delay(const float *x, const float *d, float *y, int64_t B, int64_t T, float *dl_state, int D,
+                        int warmup, float *scratch, int32_t *err_flag, hipStream_t stream);
+hipError_t launch_esr(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, double *out,
+                      hipStream_t stream);
+hipError_t launch_tcn(const float *params, int L, int C, int K, const int *dil, const float *x, float *y, int64_t B,
+                      int64_t T, float *scratch, hipStream_t stream);
+}  // namespace ntm
+
+namespace {
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char *where)
+{
+    return fail(NTM_EHIP, std::string(where) + ": " + hipGetErrorString(e));
+}
+}  // namespace
+
+extern "C" {
+
+int ntm_abi_version(void) { return 1; }
+
+const char *ntm_last_error(void) { return g_err.c_str(); }
+
+int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *w_o,
+                       const float *b_o, int H, const float *x, float *y, int64_t B, int64_t T, int64_t x_stride_b,
+                       int64_t y_stride_b, float *h_state, int variant, void *stream)
+{
+    if (H != NTM_HIDDEN) return fail(NTM_EINVAL, "ntm_gru_forward: only hidden size 64 is compiled");
+    if (B < 0 || T < 0) return fail(NTM_EINVAL, "ntm_gru_forward: negative B or T");
+    if (B == 0 || T == 0) return NTM_OK;
+    if (!w_ih || !w_hh || !b_ih || !b_hh || !w_o || !x || !y) return fail(NTM_EINVAL, "ntm_gru_forward: null pointer");
+    if (x_stride_b < T || y_stride_b < T) return fail(NTM_EINVAL, "ntm_gru_forward: stride < T");
+    ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, x_stride_b, y_stride_b};
+    if (variant == NTM_GRU_AUTO) variant = NTM_GRU_MFMA;
+    hipError_t e;
+    switch (variant) {
+        case NTM_GRU_MFMA: e = ntm::launch_gru_mfma(a, (hipStream_t)stream); break;
+        case NTM_GRU_VALU: e = ntm::launch_gru_valu(a, (hipStream_t)stream); break;
+        default: return fail(NTM_EINVAL, "ntm_gru_forward: unknown kernel variant");
+    }
+    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_gru_forward");
+}
+
+int ntm_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *w_o,
+                    const float *b_o, int H, const float *x, float *y, int64_t B, int64_t T, int64_t x_stride_b,
+                    int64_t y_stride_b, float *h_state, void *stream)
+{
+    return ntm_gru_forward_ex(w_ih, w_hh, b_ih, b_hh, w_o, b_o, H, x, y, B, T, x_stride_b, y_stride_b, h_state,
+                              NTM_GRU_AUTO, stream);
+}
+
+int64_t ntm_delay_scratch_floats(int64_t B, int64_t T, int D)
+{
+    if (B <= 0 || D <= 0 || T >= D) return 0;
+    return B * (int64_t)(D - (T < 0 ? 0 : T));
+}
+
+int ntm_delay_forward(const float *x, const float *d, float *y, int64_t B, int64_t T, float *dl_state, int D,
+                      int warmup, float *scratch, int32_t *err_flag, void *stream)
+{
+    if (B < 0 || T < 0 || D < 0) return fail(NTM_EINVAL, "ntm_delay_forward: negative size");
+    if (B == 0 || T == 0) return NTM_OK;
+    if (!x || !d || !y || (D > 0 && !dl_state)) return fail(NTM_EINVAL, "ntm_delay_forward: null pointer");
+    if (x == y) return fail(NTM_EINVAL, "ntm_delay_forward: y must not alias x");
+    if (T < D && !scratch) return fail(NTM_EINVAL, "ntm_delay_forward: scratch required when T < D");
+    hipError_t e = ntm::launch_delay(x, d, y, B, T, dl_state, D, warmup, scratch, err_flag, (hipStream_t)stream);
+    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_delay_forward");
+}
+
+int ntm_diffdel_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                            const float *w_o, int H, const float *x, const float *d, float *y, float *pre_d,
+                            int64_t B, int64_t T, float *h_state, float *dl_state, int D, int warmup, float *scratch,
+                            int32_t *err_flag, void *stream)
+{
+    if (!pre_d || pre_d == y) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: pre_d must be a distinct buffer");
+    int rc = ntm_gru_forward(w_ih, w_hh, b_ih, b_hh, w_o, nullptr, H, x, pre_d, B, T, T, T, h_state, stream);
+    if (rc != NTM_OK) return rc;
+    return ntm_delay_forward(pre_d, d, y, B, T, dl_state, D, warmup, scratch, err_flag, stream);
+}
+
+int ntm_esr_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, double *out, void *stream)
+{
+    if (B < 0 || T < 0 || skip < 0 || skip > T) return fail(NTM_EINVAL, "ntm_esr_sums: bad size");
+    if (B == 0) return NTM_OK;
+    if (!y || !t || !out) return fail(NTM_EINVAL, "ntm_esr_sums: null pointer");
+    hipError_t e = ntm::launch_esr(y, t, B, T, skip, out, (hipStream_t)stream);
+    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_esr_sums");
+}
+
+int64_t ntm_tcn_scratch_floats(int64_t B, int64_t T, int C)
+{
+    if (B <= 0 || T <= 0 || C <= 0) return 0;
+    return 2 * B * T * (int64_t)C;
+}
+
+int ntm_tcn_forward(const float *params, int L, int C, int K, const int *dil, const float *x, float *y, int64_t B,
+                    int64_t T, float *scratch, void *stream)
+{
+    if (L <= 0 || K <= 0 || B < 0 || T < 0) return fail(NTM_EINVAL, "ntm_tcn_forward: bad size");
+    if (C != 32) return fail(NTM_EINVAL, "ntm_tcn_forward: only C = 32 channels is compiled");
+    if (B == 0 || T == 0) return NTM_OK;
+    if (!params || !dil || !x || !y || !scratch) return fail(NTM_EINVAL, "ntm_tcn_forward: null pointer");
+    hipError_t e = ntm::launch_tcn(params, L, C, K, dil, x, y, B, T, scratch, (hipStream_t)stream);
+    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_tcn_forward");
+}
+
+}  // extern "C"

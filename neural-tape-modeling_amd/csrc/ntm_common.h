@@ -1,0 +1,41 @@
+// Shared device helpers for the libntm.so kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ntm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kH = 64;  // hidden size (NTM_HIDDEN)
+
+// sigma(v) = 1/(1+e^-v) on v_exp_f32 / v_rcp_f32 (both ~1 ulp).  Saturates cleanly:
+// e^-v -> inf gives 0, -> 0 gives 1.
+__device__ __forceinline__ float sigmoid_f32(float v)
+{
+    const float e = __builtin_amdgcn_exp2f(v * -1.44269504088896340736f);
+    return __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// tanh(v) = 1 - 2/(1+e^{2v}); abs error ~1e-7, exact limits +-1.
+__device__ __forceinline__ float tanh_f32(float v)
+{
+    const float e = __builtin_amdgcn_exp2f(v * 2.88539008177792681472f);
+    return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// Kernel arguments of every GRU variant (pointers are device pointers, strides in elements).
+struct GruArgs {
+    const float *w_ih, *w_hh, *b_ih, *b_hh, *w_o, *b_o;  // b_o may be null
+    const float *x;
+    float *y;
+    float *h_state;  // [B,64] in/out, may be null
+    int64_t B, T, xs, ys;
+};
+
+}  // namespace ntm
+
+namespace ntm {
+hipError_t launch_gru_mfma(const GruArgs &a, hipStream_t stream);
+hipError_t launch_gru_valu(const GruArgs &a, hipStream_t stream);
+}  // namespace ntm

@@ -1,0 +1,67 @@
+"""Multi-GPU layer: one process per GPU (torch.distributed, backend "nccl" = RCCL on ROCm).
+
+The path shards by independent audio streams: each rank owns a contiguous block
+of segments, weights (52 kB) are replicated, and nothing is exchanged on the data path.  The only
+collective is ONE all-reduce of four fp64 scalars for the loss aggregate that code/test-model.py
+computes at :386-398 (mean over segments of the per-segment loss) -- 32 bytes, latency-bound.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* if WORLD_SIZE > 1.
+    Returns (rank, world_size, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(n, rank, world):
+    """Contiguous block [lo, hi) of n streams owned by `rank` (sizes differ by at most 1)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def reduce_loss_sums(per_segment_loss, err_sums=None, group=None):
+    """Aggregate a rank's per-segment losses into the job-wide result.
+
+    per_segment_loss: (n_local,) tensor; err_sums: optional (n_local, 2) [sum e^2, sum t^2].
+    Returns dict(mean_segment_loss, segments, sum_err2, sum_tgt2): one SUM all-reduce of 4 fp64."""
+    dev = per_segment_loss.device
+    v = torch.zeros(4, dtype=torch.float64, device=dev)
+    v[0] = per_segment_loss.double().sum()
+    v[1] = per_segment_loss.numel()
+    if err_sums is not None:
+        v[2:4] = err_sums.double().sum(dim=0)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+    v = v.cpu()
+    n = int(v[1].item())
+    return {"mean_segment_loss": float(v[0] / max(n, 1)), "segments": n,
+            "sum_err2": float(v[2]), "sum_tgt2": float(v[3])}
+
+
+def max_over_ranks(value, device):
+    """MAX all-reduce of one python float (used for the benchmark's elapsed time)."""
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

@@ -1,0 +1,50 @@
+"""The model-driving part of the reference's evaluation CLI (code/test-model.py:192-247, :296-418)
+on in-memory segments: build the model from the weights-directory name, predict, cut INIT_LEN,
+per-segment loss, mean over segments -- batched over streams and sharded over ranks instead of the
+reference's BATCH_SIZE = 1 python loop (code/test-model.py:115,332)."""
+import torch
+
+from . import distributed, weights
+from .model import RNN, DiffDelRNN, esr_sums, ESR_EPS
+from .utilities import nextpow2, parse_hidden_size, parse_loss, parse_model
+
+
+def build_model(weight_name, max_delay_seconds=0.0, fs=44100, device="cuda", state_dict=None):
+    """code/test-model.py:197-233: parse the directory name, construct, load best.pth."""
+    hidden_size = parse_hidden_size(weight_name)
+    model_type = parse_model(weight_name)
+    parse_loss(weight_name)                     # raises on a malformed name, as the reference would
+    if model_type == "GRU":
+        model = RNN(input_size=1, hidden_size=hidden_size, output_size=1, skip=False)
+    elif model_type == "DiffDelGRU":
+        max_delay_n = int(1.25 * max_delay_seconds * fs)          # code/test-model.py:223
+        if max_delay_n == 0:
+            max_delay_n = 2**8
+        model = DiffDelRNN(input_size=1, hidden_size=hidden_size, output_size=1, skip=False,
+                           max_delay=max_delay_n)
+    else:
+        raise SystemExit('Something is not right!')               # code/test-model.py:232
+    model.load_state_dict(state_dict if state_dict is not None else weights.load_state_dict(weight_name))
+    return model.to(device).eval()
+
+
+def init_len(max_delay_seconds, fs=44100):
+    """INIT_LEN = nextpow2(int(max_delay * fs))  (code/test-model.py:323-324)."""
+    return nextpow2(int(max_delay_seconds * fs))
+
+
+@torch.no_grad()
+def compute_loss(model, input, target, d_traj=None, INIT_LEN=1024):
+    """code/test-model.py:332-398 for the ESR entry of the loss dict.  input/target (B,1,T) on this
+    rank (its shard of the segments); d_traj (B,1,T) in samples for DiffDelGRU.
+    Returns the job-wide dict of distributed.reduce_loss_sums plus this rank's output tensor."""
+    if isinstance(model, DiffDelRNN):
+        output, _ = model.predict(input, d_traj)
+    else:
+        output = model.predict(input)
+    s = esr_sums(output, target, skip=INIT_LEN)                   # cut first INIT_LEN samples (:367-369)
+    n = input.shape[-1] - INIT_LEN
+    per_seg = (s[:, 0] / n) / (s[:, 1] / n + ESR_EPS)
+    res = distributed.reduce_loss_sums(per_seg, s)
+    res["ESR"] = res.pop("mean_segment_loss")
+    return res, output

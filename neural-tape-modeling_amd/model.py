@@ -1,0 +1,290 @@
+"""Host-side mirror of the reference's model objects for the tape-nonlinearity forward path.
+
+Same class names, constructor arguments, state_dict keys, methods, argument order, return arity and
+error behaviour as code/model.py of the reference (RNN :20-246, TimeVaryingDelayLine :249-332,
+DiffDelRNN :335-653), so a caller such as code/test-model.py:217-234,346,353 can switch by changing
+one import.  The arithmetic runs in libntm.so (hand-written HIP, gfx950); torch is used for device
+memory, streams and parameter bookkeeping only.  There is NO CPU path: a non-HIP tensor raises.
+
+Deliberate differences from the reference (documented in DESIGN.md):
+  * predict() works for any batch size: the zero-input warm-up (identical for every stream) is run
+    once with B=1 and its state broadcast -- per stream this is exactly the reference's B=1 maths
+    (the reference raises for B>1).
+  * predict() runs the whole sequence in one persistent launch; `segment_length=2048` reproduces
+    the reference's chunk loop (same result, state is carried either way).
+  * Training entry points (train_epoch / validate / detach_*) are out of scope.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ptr
+
+
+class _GRUParams(torch.nn.Module):
+    """Parameter container with torch.nn.GRU's names/shapes/init (single layer, gate order r,z,n)."""
+
+    def __init__(self, input_size, hidden_size):
+        super().__init__()
+        k = 1.0 / np.sqrt(hidden_size)
+        mk = lambda *shape: torch.nn.Parameter(torch.empty(*shape).uniform_(-k, k), requires_grad=False)  # noqa: E731
+        self.weight_ih_l0 = mk(3 * hidden_size, input_size)
+        self.weight_hh_l0 = mk(3 * hidden_size, hidden_size)
+        self.bias_ih_l0 = mk(3 * hidden_size)
+        self.bias_hh_l0 = mk(3 * hidden_size)
+
+
+class _LinearParams(torch.nn.Module):
+    """Parameter container with torch.nn.Linear's names/shapes/init."""
+
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        k = 1.0 / np.sqrt(in_features)
+        self.weight = torch.nn.Parameter(torch.empty(out_features, in_features).uniform_(-k, k),
+                                         requires_grad=False)
+        if bias:
+            self.bias = torch.nn.Parameter(torch.empty(out_features).uniform_(-k, k), requires_grad=False)
+        else:
+            self.register_parameter("bias", None)
+
+
+def _require_hip(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: tensor is on '{t.device}'; this engine runs on a HIP device only "
+                           "(no CPU fallback)")
+
+
+def _as_bt(x, what):
+    """(B,1,T) float32/float64 -> contiguous float32 [B,T] view, like code/model.py:76-77."""
+    if x.dim() != 3:
+        raise RuntimeError(f"{what}: expected (N_BATCHES, N_CHANNELS, N_SAMPLES), got {tuple(x.shape)}")
+    if x.shape[1] != 1:
+        raise RuntimeError(f"{what}: input_size 1 expected, got {x.shape[1]} channels")
+    _require_hip(x, what)
+    x = x.float() if x.dtype != torch.float32 else x
+    return x.contiguous().view(x.shape[0], x.shape[2])
+
+
+class _GRUHead(torch.nn.Module):
+    """GRU(1,H) + Linear(H,1[,bias]) state and launch logic shared by RNN and DiffDelRNN."""
+
+    kernel_variant = "auto"      # "auto" | "mfma" | "valu"  (see include/ntm.h NTM_GRU_*)
+
+    def _init_net(self, input_size, hidden_size, output_size, skip, head_bias):
+        if input_size != 1 or output_size != 1:
+            raise ValueError("only input_size = output_size = 1 is built (every reference checkpoint and "
+                             "caller uses 1: code/test-model.py:123-124)")
+        if hidden_size != 64:
+            raise ValueError("only hidden_size = 64 is compiled (all shipped checkpoints are HS[64])")
+        self.input_size, self.hidden_size, self.output_size, self.skip = input_size, hidden_size, output_size, skip
+        self.GRU = _GRUParams(input_size, hidden_size)
+        self.output = _LinearParams(hidden_size, output_size, bias=head_bias)
+        self.hidden = None
+
+    def _hidden_for(self, B, device):
+        H = self.hidden_size
+        if self.hidden is None:
+            return torch.zeros(1, B, H, device=device, dtype=torch.float32)
+        if tuple(self.hidden.shape) != (1, B, H):
+            raise RuntimeError(f"Expected hidden size (1, {B}, {H}), got {list(self.hidden.shape)}")
+        return self.hidden.to(device=device, dtype=torch.float32).clone()
+
+    def _gru(self, xbt):
+        """xbt [B,T] fp32 on HIP -> y [B,T]; carries self.hidden (code/model.py:81-82)."""
+        B, T = xbt.shape
+        _require_hip(self.GRU.weight_hh_l0, "model parameters (call .to('cuda'))")
+        h = self._hidden_for(B, xbt.device)
+        y = torch.empty_like(xbt)
+        g, o = self.GRU, self.output
+        rc = _lib.lib().ntm_gru_forward_ex(
+            ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0), ptr(o.weight),
+            ptr(o.bias), self.hidden_size, ptr(xbt), ptr(y), B, T, T, T, ptr(h),
+            _lib.VARIANTS[self.kernel_variant], _lib.current_stream())
+        _lib.check(rc, "ntm_gru_forward")
+        self.hidden = h
+        return y
+
+
+class RNN(_GRUHead):
+    """GRU + fully connected output layer (reference: code/model.py:20-246)."""
+
+    def __init__(self, input_size=1, hidden_size=8, output_size=1, skip=False):
+        super().__init__()
+        self._init_net(input_size, hidden_size, output_size, skip, head_bias=True)
+        self.initialize_hidden()
+
+    def initialize_hidden(self):
+        """Initialize GRU hidden state to zeros (code/model.py:50-52)."""
+        self.hidden = None
+
+    def warm_start(self):
+        """Process 1024 samples of silence, B=1 (code/model.py:58-65)."""
+        START_LEN = 2**10
+        with torch.no_grad():
+            x = torch.zeros((1, 1, START_LEN), device=self.GRU.weight_hh_l0.device)
+            _ = self(x)
+
+    @torch.no_grad()
+    def forward(self, x):
+        """x (N_BATCHES, 1, N_SAMPLES) -> y same shape; stateful (code/model.py:67-88)."""
+        xbt = _as_bt(x, "RNN.forward")
+        y = self._gru(xbt)
+        if self.skip:
+            y += xbt
+        return y.view(xbt.shape[0], 1, xbt.shape[1])
+
+    @torch.no_grad()
+    def predict(self, input, segment_length=None):
+        """initialize_hidden + warm_start + forward over the sequence (code/model.py:218-246)."""
+        B, T = input.shape[0], input.shape[-1]
+        self.initialize_hidden()
+        self.warm_start()
+        if B != 1:
+            self.hidden = self.hidden.expand(1, B, self.hidden_size).contiguous()
+        if segment_length is None:
+            return self.forward(input)
+        output = torch.empty(input.shape, device=input.device, dtype=torch.float32)
+        for i in range(int(np.ceil(T / segment_length))):
+            sl = slice(i * segment_length, (i + 1) * segment_length)
+            output[:, :, sl] = self.forward(input[:, :, sl])
+        return output
+
+
+class TimeVaryingDelayLine(torch.nn.Module):
+    """Time-varying feed-forward delay line, linear interpolation (reference: code/model.py:249-332)."""
+
+    def __init__(self, max_delay=40000, channels=1):
+        super().__init__()
+        if channels != 1:
+            raise ValueError("only 1 channel is built (reference default, code/model.py:251)")
+        self.max_delay = max_delay
+        # like the reference, batch 2 until init_buffer() is called (code/model.py:267)
+        self.buffer = torch.zeros(2, channels, max_delay)
+        self._err = None
+
+    def init_buffer(self, N, max_d):
+        """Zero buffer for mini-batch size N; overwrites max_delay (code/model.py:326-332)."""
+        device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.max_delay = max_d
+        self.buffer = torch.zeros(N, 1, self.max_delay).to(device)
+
+    def _run(self, xbt, dbt, warmup):
+        B, T = xbt.shape
+        D = int(self.max_delay)
+        if self.buffer.shape[0] != B or self.buffer.shape[2] != D:
+            raise RuntimeError(f"Sizes of tensors must match: buffer {list(self.buffer.shape)} vs input batch {B}")
+        buf = self.buffer.to(device=xbt.device, dtype=torch.float32).contiguous().clone()
+        y = torch.empty_like(xbt)
+        L = _lib.lib()
+        ns = L.ntm_delay_scratch_floats(B, T, D)
+        scratch = torch.empty(max(ns, 1), device=xbt.device, dtype=torch.float32)
+        if self._err is None or self._err.device != xbt.device:
+            self._err = torch.zeros(1, device=xbt.device, dtype=torch.int32)
+        rc = L.ntm_delay_forward(ptr(xbt), ptr(dbt), ptr(y), B, T, ptr(buf), D, int(bool(warmup)), ptr(scratch),
+                                 ptr(self._err), _lib.current_stream())
+        _lib.check(rc, "ntm_delay_forward")
+        # the reference asserts before touching anything (code/model.py:284); the kernels skip all
+        # writes when the flag is set, so state is equally untouched.
+        assert int(self._err.item()) == 0, "max_delay >= max(dt) violated"
+        self.buffer = buf
+        return y
+
+    @torch.no_grad()
+    def forward(self, x, dt, warmup=False):
+        """x, dt (N,1,T), dt in samples -> y (N,1,T) (code/model.py:269-320)."""
+        xbt = _as_bt(x, "TimeVaryingDelayLine.forward")
+        dbt = _as_bt(dt, "TimeVaryingDelayLine.forward")
+        if dbt.shape != xbt.shape:
+            raise RuntimeError(f"shape mismatch: x {tuple(x.shape)} vs dt {tuple(dt.shape)}")
+        return self._run(xbt, dbt, warmup).view(xbt.shape[0], 1, xbt.shape[1])
+
+
+class DiffDelRNN(_GRUHead):
+    """RNN (bias-free head) + differentiable delay line (reference: code/model.py:335-653)."""
+
+    def __init__(self, input_size=1, hidden_size=8, output_size=1, skip=False, max_delay=10000):
+        super().__init__()
+        self._init_net(input_size, hidden_size, output_size, skip, head_bias=False)
+        self.max_delay = max_delay
+        self.diffdel = TimeVaryingDelayLine(max_delay=max_delay)
+        self.initialize_hidden(2, max_delay)     # as the reference does (code/model.py:370)
+
+    def initialize_hidden(self, N, max_D):
+        """hidden <- None; delay buffer <- zeros(N,1,int(max_D)+1) (code/model.py:372-375)."""
+        self.hidden = None
+        self.diffdel.init_buffer(N, int(max_D) + 1)
+
+    def warm_start(self):
+        """1024 samples of silence with zero delay, B=1 (code/model.py:382-391)."""
+        START_LEN = 2**10
+        dev = self.GRU.weight_hh_l0.device
+        with torch.no_grad():
+            x = torch.zeros((1, 1, START_LEN), device=dev)
+            d_traj = torch.zeros((1, 1, START_LEN), device=dev)
+            _, __ = self(x, d_traj)
+
+    @torch.no_grad()
+    def forward(self, x, del_traj, warmup=False):
+        """(x, del_traj) (N,1,T) -> (y, pre_d) (code/model.py:393-424)."""
+        xbt = _as_bt(x, "DiffDelRNN.forward")
+        dbt = _as_bt(del_traj, "DiffDelRNN.forward")
+        if dbt.shape != xbt.shape:
+            raise RuntimeError(f"shape mismatch: x {tuple(x.shape)} vs del_traj {tuple(del_traj.shape)}")
+        pre = self._gru(xbt)
+        if self.skip:
+            pre += xbt
+        y = self.diffdel._run(pre, dbt, warmup)
+        B, T = xbt.shape
+        return y.view(B, 1, T), pre.view(B, 1, T)
+
+    @torch.no_grad()
+    def predict(self, input, d_traj, segment_length=None):
+        """initialize_hidden + warm_start + forward (code/model.py:618-653); any batch size."""
+        B, T = input.shape[0], input.shape[-1]
+        self.initialize_hidden(1, self.max_delay)
+        self.warm_start()
+        if B != 1:
+            self.hidden = self.hidden.expand(1, B, self.hidden_size).contiguous()
+            self.diffdel.buffer = self.diffdel.buffer.expand(B, 1, -1).contiguous()
+        if segment_length is None:
+            return self.forward(input, d_traj)
+        output = torch.empty(input.shape, device=input.device, dtype=torch.float32)
+        output_pre_d = torch.empty(input.shape, device=input.device, dtype=torch.float32)
+        for i in range(int(np.ceil(T / segment_length))):
+            sl = slice(i * segment_length, (i + 1) * segment_length)
+            output[:, :, sl], output_pre_d[:, :, sl] = self.forward(input[:, :, sl], d_traj[:, :, sl])
+        return output, output_pre_d
+
+
+# ------------------------------------------------------------------------------------------
+# ESR (the loss that follows the path in code/test-model.py:250-254,386-388)
+# ------------------------------------------------------------------------------------------
+ESR_EPS = 1e-5
+
+
+@torch.no_grad()
+def esr_sums(output, target, skip=0):
+    """Per-stream [sum (t-y)^2, sum t^2] over samples [skip,T) as a (B,2) float64 HIP tensor."""
+    y = _as_bt(output, "esr_sums")
+    t = _as_bt(target, "esr_sums")
+    B, T = y.shape
+    out = torch.empty(B, 2, device=y.device, dtype=torch.float64)
+    rc = _lib.lib().ntm_esr_sums(ptr(y), ptr(t), B, T, int(skip), ptr(out), _lib.current_stream())
+    _lib.check(rc, "ntm_esr_sums")
+    return out
+
+
+def esr_per_segment(output, target, skip=0):
+    """CoreAudioML ESRLoss per stream: mean(e^2) / (mean(t^2) + 1e-5) over samples [skip,T)."""
+    s = esr_sums(output, target, skip)
+    n = output.shape[-1] - skip
+    return (s[:, 0] / n) / (s[:, 1] / n + ESR_EPS)
+
+
+class ESRLoss(torch.nn.Module):
+    """ESR of a whole (B,1,T) tensor, as `loss_fcn(output, target)` in code/test-model.py:386-388."""
+
+    def forward(self, output, target):
+        s = esr_sums(output, target).sum(dim=0)
+        n = output.numel()
+        return ((s[0] / n) / (s[1] / n + ESR_EPS)).float()

@@ -36,21 +36,26 @@
 
 static inline float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
-/* one stream: x[T] -> y[T], h[H] in/out */
-static void gru_stream(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+/* one stream: x[T] -> y[T], h[H] in/out.  wt = W_hh transposed [H][3H] so the inner loop runs over
+ * the 3H outputs (vectorisable) while every output still accumulates its products in k = 0..H-1
+ * order, i.e. the same sequential fp32 sum as the plain dot-product form. */
+__attribute__((target_clones("avx2", "default")))
+static void gru_stream(const float *w_ih, const float *wt, const float *b_ih, const float *b_hh,
                        const float *w_o, const float *b_o, int H, const float *x, float *y,
                        int64_t T, float *h)
 {
-    float *gh = (float *)malloc(sizeof(float) * 3 * (size_t)H);
+    const int G = 3 * H;
+    float *gh = (float *)malloc(sizeof(float) * (size_t)G);
     float *hn = (float *)malloc(sizeof(float) * (size_t)H);
     for (int64_t t = 0; t < T; ++t) {
         const float xt = x[t];
-        for (int g = 0; g < 3 * H; ++g) {
-            const float *row = w_hh + (size_t)g * H;
-            float acc = 0.0f;
-            for (int k = 0; k < H; ++k) acc += row[k] * h[k];
-            gh[g] = acc + b_hh[g];
+        for (int g = 0; g < G; ++g) gh[g] = 0.0f;
+        for (int k = 0; k < H; ++k) {
+            const float hk = h[k];
+            const float *col = wt + (size_t)k * G;
+            for (int g = 0; g < G; ++g) gh[g] += col[g] * hk;
         }
+        for (int g = 0; g < G; ++g) gh[g] += b_hh[g];
         float yo = 0.0f;
         for (int j = 0; j < H; ++j) {
             const float gi_r = w_ih[j] * xt + b_ih[j];
@@ -69,14 +74,25 @@ static void gru_stream(const float *w_ih, const float *w_hh, const float *b_ih, 
     free(hn);
 }
 
+static float *transpose_whh(const float *w_hh, int H)
+{
+    const int G = 3 * H;
+    float *wt = (float *)malloc(sizeof(float) * (size_t)G * (size_t)H);
+    for (int g = 0; g < G; ++g)
+        for (int k = 0; k < H; ++k) wt[(size_t)k * G + g] = w_hh[(size_t)g * H + k];
+    return wt;
+}
+
 /* code/model.py:81-82.  h_state [B,H] in/out (caller passes zeros for hidden=None). */
 int ntmo_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
                      const float *w_o, const float *b_o, int H, const float *x, float *y,
                      int64_t B, int64_t T, float *h_state)
 {
     if (H <= 0 || B < 0 || T < 0) return -1;
+    float *wt = transpose_whh(w_hh, H);
     for (int64_t b = 0; b < B; ++b)
-        gru_stream(w_ih, w_hh, b_ih, b_hh, w_o, b_o, H, x + b * T, y + b * T, T, h_state + b * H);
+        gru_stream(w_ih, wt, b_ih, b_hh, w_o, b_o, H, x + b * T, y + b * T, T, h_state + b * H);
+    free(wt);
     return 0;
 }
 
@@ -85,9 +101,11 @@ int ntmo_gru_forward_mt(const float *w_ih, const float *w_hh, const float *b_ih,
                         int64_t B, int64_t T, float *h_state, int threads)
 {
     if (H <= 0 || B < 0 || T < 0) return -1;
+    float *wt = transpose_whh(w_hh, H);
 #pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
     for (int64_t b = 0; b < B; ++b)
-        gru_stream(w_ih, w_hh, b_ih, b_hh, w_o, b_o, H, x + b * T, y + b * T, T, h_state + b * H);
+        gru_stream(w_ih, wt, b_ih, b_hh, w_o, b_o, H, x + b * T, y + b * T, T, h_state + b * H);
+    free(wt);
     return 0;
 }
 

@@ -1,0 +1,113 @@
+"""CPU: host logic, the C-ABI surface, name parsers, weights, and the no-fallback guarantee."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import ntm_amd
+from helpers import GOLDEN, ROOT, state_dict_np
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "ntm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ntm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_cabi_library_loads_and_exports_every_declared_symbol():
+    syms = header_symbols()
+    assert {"ntm_gru_forward", "ntm_gru_forward_ex", "ntm_delay_forward", "ntm_diffdel_gru_forward",
+            "ntm_esr_sums", "ntm_tcn_forward", "ntm_last_error", "ntm_abi_version"} <= set(syms)
+    lib = ctypes.CDLL(ntm_amd._lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), f"libntm.so does not export {s}"
+    assert set(ntm_amd._lib._SIGNATURES) == set(syms)       # the ctypes table covers the whole header
+    assert ntm_amd._lib.lib().ntm_abi_version() == 1
+
+
+def test_cabi_pure_host_entry_points():
+    L = ntm_amd._lib.lib()
+    assert L.ntm_delay_scratch_floats(4, 100, 37) == 0
+    assert L.ntm_delay_scratch_floats(4, 20, 37) == 4 * 17
+    assert L.ntm_tcn_scratch_floats(2, 100, 32) == 2 * 2 * 100 * 32
+    # argument validation happens before anything touches a device
+    assert L.ntm_gru_forward(None, None, None, None, None, None, 8, None, None, 1, 1, 1, 1, None, None) == -1
+    assert b"64" in L.ntm_last_error()
+    assert L.ntm_esr_sums(None, None, 1, 10, 11, None, None) == -1
+
+
+def test_name_parsers_match_reference_table():
+    tab = json.load(open(os.path.join(GOLDEN, "g7_name_parsers.json")))
+    assert len(tab["names"]) == 44
+    for row in tab["names"]:
+        assert ntm_amd.parse_model(row["name"]) == row["model"]
+        assert ntm_amd.parse_hidden_size(row["name"]) == row["hidden"]
+        assert ntm_amd.parse_loss(row["name"]) == row["loss"]
+    for n, v in tab["nextpow2"].items():
+        assert ntm_amd.nextpow2(int(n)) == v
+    with pytest.raises(AttributeError):                        # reference behaviour on its own default
+        ntm_amd.parse_loss("GRU-HS[64]-DS[foo]")              # --WEIGHTS (no -L[..]): re.search -> None
+
+
+def test_state_dict_protocol():
+    m = ntm_amd.RNN(input_size=1, hidden_size=64, output_size=1, skip=False)
+    assert list(m.state_dict()) == ["GRU.weight_ih_l0", "GRU.weight_hh_l0", "GRU.bias_ih_l0",
+                                    "GRU.bias_hh_l0", "output.weight", "output.bias"]
+    assert sum(p.numel() for p in m.parameters()) == 12929
+    d = ntm_amd.DiffDelRNN(input_size=1, hidden_size=64, output_size=1, skip=False, max_delay=1846)
+    assert "output.bias" not in d.state_dict() and sum(p.numel() for p in d.parameters()) == 12928
+    assert d.diffdel.max_delay == 1847 and tuple(d.diffdel.buffer.shape) == (2, 1, 1847)   # code/model.py:370-375
+    for name in ntm_amd.weights.available():
+        sd = ntm_amd.weights.load_state_dict(name)
+        ref = state_dict_np(name)
+        assert set(sd) == set(ref)
+        model = ntm_amd.harness.build_model(name, device="cpu")
+        for k, v in model.state_dict().items():
+            assert np.array_equal(v.numpy(), ref[k])
+    with pytest.raises(RuntimeError):                          # strict load like torch: bias key missing
+        m.load_state_dict(ntm_amd.weights.load_state_dict(ntm_amd.weights.W_DIFFDEL))
+    with pytest.raises(ValueError):
+        ntm_amd.RNN(1, 8, 1)                                   # reference default H=8 is not compiled
+
+
+def test_no_cpu_fallback():
+    m = ntm_amd.harness.build_model(ntm_amd.weights.W_GRU, device="cpu")
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        m(torch.zeros(1, 1, 16))
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        m.predict(torch.zeros(1, 1, 16))
+    d = ntm_amd.TimeVaryingDelayLine(max_delay=8)
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        d(torch.zeros(2, 1, 16), torch.zeros(2, 1, 16))
+    with pytest.raises(RuntimeError, match="HIP device only"):
+        ntm_amd.esr_sums(torch.zeros(1, 1, 4), torch.zeros(1, 1, 4))
+    # the product never imports, loads or links the oracle
+    src_dir = os.path.join(ROOT, "neural-tape-modeling_amd")
+    for dirpath, _, files in os.walk(src_dir):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), fn
+                assert "ntm_oracle" not in text and "ntmo_" not in text, fn
+
+
+def test_shape_errors():
+    m = ntm_amd.harness.build_model(ntm_amd.weights.W_GRU, device="cpu")
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(4, 16))
+    with pytest.raises(RuntimeError, match="input_size 1"):
+        m(torch.zeros(1, 2, 16))
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 7, 4096, 32768):
+        for world in (1, 2, 3, 8):
+            spans = [ntm_amd.distributed.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
