@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void delay_apply_kernel(const float *x, const 
                                                           int64_t T, const float *buf, int D, int warmup,
                                                           const int32_t *flag)
 {
+#pragma clang fp contract(off)   // products and the sum must round separately (bit-exact parity)
     if (flag && *flag) return;
     const int64_t b = blockIdx.x;
     const float *xb = x + b * T, *db = d + b * T, *bb = buf + b * (int64_t)D;
@@ -35,11 +36,12 @@ __global__ __launch_bounds__(256) void delay_apply_kernel(const float *x, const 
         for (int tap = 1; tap >= 0; --tap) {          // m = k+1 first, then m = k (reference sum order)
             const float mf = kf + (float)tap;
             if (mf < 0.0f || mf > (float)D) continue;
-            const float w = __fsub_rn(1.0f, fabsf(__fsub_rn(mf, dn)));
+            const float w = 1.0f - fabsf(mf - dn);
             if (!(w > 0.0f)) continue;
             const int64_t src = n - (int64_t)mf;
             const float xv = src >= 0 ? xb[src] : bb[D + src];
-            acc = __fadd_rn(acc, __fmul_rn(w, xv));
+            const float prod = w * xv;
+            acc = acc + prod;
         }
         yb[n] = acc;
     }
