@@ -89,8 +89,8 @@ def cpu_baseline(w_name, seconds_budget=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="segments per GPU")
     ap.add_argument("--samples", type=int, default=65536, help="samples per segment")
     ap.add_argument("--variant", default="auto", choices=["auto", "mfma", "valu"])
@@ -161,7 +161,7 @@ def main():
     kern_s = float(np.mean(kern_ms)) / 1e3
     tflops = FLOP_PER_SAMPLE * B * T / kern_s / 1e12
     hbm_gbs = BYTES_PER_SAMPLE * B * T / kern_s / 1e9
-    checks = {"esr_vs_first_pass": res["ESR"] if res else None, "segments": res["segments"] if res else None}
+    checks = {"esr_vs_first_pass": res["mean_segment_loss"] if res else None, "segments": res["segments"] if res else None}
     if gold is not None:
         yg = y[0, 0].cpu().numpy()
         e = gold["y"][0, 0] - yg
