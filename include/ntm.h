@@ -37,6 +37,7 @@ extern "C" {
 #define NTM_GRU_AUTO 0  /* pick by B                                                        */
 #define NTM_GRU_MFMA 1  /* 16 streams / workgroup, 4 waves, v_mfma_f32_16x16x4_f32, h in LDS */
 #define NTM_GRU_VALU 2  /* 2 streams / wavefront, W_hh in VGPRs, h broadcast through LDS     */
+#define NTM_GRU_MFMA2 3 /* as MFMA, own-quarter-first step order: LDS exchange hidden by MFMAs */
 
 /* ABI version of this header; bumped on any signature change. */
 int ntm_abi_version(void);
@@ -67,6 +68,19 @@ int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, 
                        const float *w_o, const float *b_o, int H, const float *x, float *y,
                        int64_t B, int64_t T, int64_t x_stride_b, int64_t y_stride_b,
                        float *h_state, int variant, void *stream);
+
+/*
+ * DIAGNOSTIC ONLY (never timed): the MFMA kernel with s_memtime stamps.  stamps[(B+15)/16][4][6]
+ * (device, uint64) receives per-wave cycle sums of  LDS read | phase A | phase B | tail | LDS
+ * write | barrier  over the whole launch.  Outputs are the same as ntm_gru_forward.
+ */
+int ntm_debug_gru_stamps(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                         const float *w_o, const float *b_o, const float *x, float *y, int64_t B,
+                         int64_t T, float *h_state, uint64_t *stamps, void *stream);
+
+/* DIAGNOSTIC ONLY: the in-register 4x4 lane-group transpose used by the MFMA2 kernel, applied to one
+ * 256-thread block: in/out [256][4] floats (device). */
+int ntm_debug_transpose4(const float *in, float *out, void *stream);
 
 /*
  * Replaces TimeVaryingDelayLine.forward(x, dt, warmup), code/model.py:269-320.

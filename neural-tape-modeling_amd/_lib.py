@@ -8,10 +8,10 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libntm.so")
+LIB_PATH = os.environ.get("NTM_LIB_PATH") or os.path.join(_HERE, "libntm.so")   # override: kernel A/B builds
 
-NTM_GRU_AUTO, NTM_GRU_MFMA, NTM_GRU_VALU = 0, 1, 2
-VARIANTS = {"auto": NTM_GRU_AUTO, "mfma": NTM_GRU_MFMA, "valu": NTM_GRU_VALU}
+NTM_GRU_AUTO, NTM_GRU_MFMA, NTM_GRU_VALU, NTM_GRU_MFMA2 = 0, 1, 2, 3
+VARIANTS = {"auto": NTM_GRU_AUTO, "mfma": NTM_GRU_MFMA, "valu": NTM_GRU_VALU, "mfma2": NTM_GRU_MFMA2}
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -22,6 +22,8 @@ _SIGNATURES = {
     "ntm_last_error": (ctypes.c_char_p, []),
     "ntm_gru_forward": (_int, [_vp] * 6 + [_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "ntm_gru_forward_ex": (_int, [_vp] * 6 + [_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp]),
+    "ntm_debug_gru_stamps": (_int, [_vp] * 6 + [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "ntm_debug_transpose4": (_int, [_vp, _vp, _vp]),
     "ntm_delay_forward": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _int, _int, _vp, _vp, _vp]),
     "ntm_delay_scratch_floats": (_i64, [_i64, _i64, _int]),
     "ntm_diffdel_gru_forward": (_int, [_vp] * 5 + [_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _int,

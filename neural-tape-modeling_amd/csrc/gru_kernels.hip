@@ -42,8 +42,23 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c)
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// STAMP = true is a DIAGNOSTIC build (ntm_debug_gru_stamps): s_memtime stamps split every step into
+// read | phase A | phase B | tail | write | barrier and the per-wave sums go to a.dbg.  Never timed.
+#define NTM_STAMP(k)                                                                        \
+    if constexpr (STAMP) {                                                                  \
+        unsigned long long now_;                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        seg[k] += now_ - last_;                                                             \
+        last_ = now_;                                                                       \
+    }
+
+template <bool STAMP>
 __global__ __launch_bounds__(256, 1) void gru_mfma_kernel(GruArgs a)
 {
+    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, last_ = 0;
+    (void)seg; (void)last_;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *hb = smem;                   // [2][HB]
     float *xb = hb + 2 * HB;            // [2][SG][XS]
@@ -124,6 +139,9 @@ __global__ __launch_bounds__(256, 1) void gru_mfma_kernel(GruArgs a)
     int64_t next_flush = 0;
     __syncthreads();
 
+    if constexpr (STAMP) {
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
+    }
     for (int64_t t = 0; t <= T; ++t) {
         const int cur = (int)(t & 1);
         // (1) h_{t-1} of stream j, units 16q..16q+15: the B operands of all 16 K-steps
@@ -136,18 +154,19 @@ __global__ __launch_bounds__(256, 1) void gru_mfma_kernel(GruArgs a)
                 hB[4 * c + 0] = v4.x; hB[4 * c + 1] = v4.y; hB[4 * c + 2] = v4.z; hB[4 * c + 3] = v4.w;
             }
         }
-        // (2) head of the PREVIOUS step: partial of y_{t-1} over units 16q..16q+15 (wave 0 stores;
-        //     the four q-partials are summed when the tile is flushed)
-        if (t > 0 && w == 0) {
-            float p = 0.0f;
+        if (t == T) {
+            // last iteration: only the head of step T-1 is left
+            if (w == 0) {
+                float p = 0.0f;
 #pragma unroll
-            for (int s = 0; s < 16; ++s) p = __builtin_fmaf(wo[s], hB[s], p);
-            const int64_t tp = t - 1;
-            yp[((tp >> 6) & 1) * 4 * YP_Q + q * YP_Q + j * XS + (tp & 63)] = p;
+                for (int s = 0; s < 16; ++s) p = __builtin_fmaf(wo[s], hB[s], p);
+                const int64_t tp = t - 1;
+                yp[((tp >> 6) & 1) * 4 * YP_Q + q * YP_Q + j * XS + (tp & 63)] = p;
+            }
+            break;
         }
-        if (t == T) break;
 
-        // (3) tile housekeeping, once per 64 steps each
+        // (2) tile housekeeping, once per 64 steps each
         const int ph = (int)(t & 63);
         const int64_t tile = t >> 6;
         if (ph == 1) {
@@ -156,44 +175,88 @@ __global__ __launch_bounds__(256, 1) void gru_mfma_kernel(GruArgs a)
         } else if (ph == 33) {
             if ((tile + 1) * TT < T) store_x_tile(tile + 1, xr);
         }
+        NTM_STAMP(0)   // LDS reads of h_{t-1} (+ tile housekeeping)
 
-        // (4) input contribution + biases as the MFMA C operands
+        // (3) phase A: W_hr.h and W_hn.h as two interleaved MFMA chains (32 MFMAs).  Everything else
+        //     that does not depend on them rides in their shadow, at most three VALU ops per MFMA
+        //     pair: the r/z/n input terms (C operands), and the head partial of the PREVIOUS step
+        //     (y_{t-1} over units 16q..16q+15; the four q-partials are summed at tile flush).
+        //     Empty asm statements pin the order: a tied value must be complete before the pin and
+        //     may only be consumed after it, so neither MFMAs nor VALU ops drift between gaps.
         const float xt = xb[(tile & 1) * SG * XS + j * XS + ph];
-        f32x4 acc_r, acc_za, acc_zb, acc_n;
-        float gin[4];
+        f32x4 acc_r, acc_za, acc_zb, acc_n, gin;
+        float hp = 0.0f;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            acc_r[v] = __builtin_fmaf(wir[v], xt, br[v]);
-            acc_za[v] = __builtin_fmaf(wiz[v], xt, bz[v]);
-            acc_zb[v] = 0.0f;
-            acc_n[v] = bhn[v];
-            gin[v] = __builtin_fmaf(win[v], xt, bin_[v]);
-        }
-        // (5) W_hh . h on the matrix pipe: r and n first (two independent chains), then z split in
-        //     two chains so the r/n gate math overlaps z's MFMAs.
+        for (int v = 0; v < 4; ++v) acc_n[v] = bhn[v];
+        acc_n = mfma16(An[0], hB[0], acc_n);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            acc_r = mfma16(Ar[s], hB[s], acc_r);
+        for (int v = 0; v < 4; ++v) acc_r[v] = __builtin_fmaf(wir[v], xt, br[v]);
+        acc_r = mfma16(Ar[0], hB[0], acc_r);
+#pragma unroll
+        for (int s = 1; s < 16; ++s) {
+            hp = __builtin_fmaf(wo[s - 1], hB[s - 1], hp);
+            if (s == 15) hp = __builtin_fmaf(wo[15], hB[15], hp);
+            if (s <= 4) acc_za[s - 1] = __builtin_fmaf(wiz[s - 1], xt, bz[s - 1]);
+            else if (s <= 8) gin[s - 5] = __builtin_fmaf(win[s - 5], xt, bin_[s - 5]);
             acc_n = mfma16(An[s], hB[s], acc_n);
+            acc_r = mfma16(Ar[s], hB[s], acc_r);
+            if (s < 4) asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(hp));
+            else if (s < 8) asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(hp), "+v"(acc_za));
+            else asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(hp), "+v"(acc_za), "+v"(gin));
+        }
+        if (t > 0 && w == 0) {
+            const int64_t tp = t - 1;
+            yp[((tp >> 6) & 1) * 4 * YP_Q + q * YP_Q + j * XS + (tp & 63)] = hp;
         }
 #pragma unroll
-        for (int s = 0; s < 16; s += 2) {
-            acc_za = mfma16(Az[s], hB[s], acc_za);
-            acc_zb = mfma16(Az[s + 1], hB[s + 1], acc_zb);
+        for (int v = 0; v < 4; ++v) acc_zb[v] = 0.0f;
+        NTM_STAMP(1)   // phase A issue
+        // (4) phase B: W_hz.h as two chains (16 MFMAs).  Underneath, the r and n gate math as 44
+        //     micro-ops, stage-major over the lane's 4 elements so that consecutive ops of one
+        //     element are >= one MFMA slot apart (no dependent-VALU stall in front of an MFMA):
+        //       e = -log2e*acc_r | 2^e | 1+e | 1/e (= r) | r*acc_n+gi_n | 2log2e*e | 2^e | 1+e | 1/e |
+        //       n = 1-2e | dn = h-n
+        float e[4], dn[4];
+        acc_za = mfma16(Az[0], hB[0], acc_za);
+#pragma unroll
+        for (int m = 1; m < 16; ++m) {
+#pragma unroll
+            for (int i = 3 * (m - 1); i < 3 * m && i < 44; ++i) {
+                const int st = i >> 2, v = i & 3;
+                if (st == 0) e[v] = acc_r[v] * -1.44269504088896340736f;
+                else if (st == 1 || st == 6) e[v] = __builtin_amdgcn_exp2f(e[v]);
+                else if (st == 2 || st == 7) e[v] = 1.0f + e[v];
+                else if (st == 3 || st == 8) e[v] = __builtin_amdgcn_rcpf(e[v]);
+                else if (st == 4) e[v] = __builtin_fmaf(e[v], acc_n[v], gin[v]);
+                else if (st == 5) e[v] = e[v] * 2.88539008177792681472f;
+                else if (st == 9) e[v] = __builtin_fmaf(-2.0f, e[v], 1.0f);
+                else dn[v] = hold[v] - e[v];
+            }
+            if (m & 1) acc_zb = mfma16(Az[m], hB[m], acc_zb);
+            else acc_za = mfma16(Az[m], hB[m], acc_za);
+            asm volatile("" : "+v"(acc_za), "+v"(acc_zb), "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]));
         }
-        // (6) gates (lane-local: stream j, units 16w+4q+v)
+        asm volatile("" : "+v"(dn[0]), "+v"(dn[1]), "+v"(dn[2]), "+v"(dn[3]));
+        NTM_STAMP(2)   // phase B issue
+        // (5) phase C (exposed tail): z gate and blend  h' = n + z (h - n)
         f32x4 hn;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const float r = sigmoid_f32(acc_r[v]);
-            const float n = tanh_f32(__builtin_fmaf(r, acc_n[v], gin[v]));
             const float z = sigmoid_f32(acc_za[v] + acc_zb[v]);
-            hold[v] = __builtin_fmaf(z, hold[v] - n, n);
+            hold[v] = __builtin_fmaf(z, dn[v], e[v]);
             hn[v] = hold[v];
         }
+        asm volatile("" : "+v"(hn));
+        NTM_STAMP(3)   // tail VALU (includes waiting for the last MFMAs)
         // (7) publish h_t into the other buffer; one barrier per step
         *(f32x4 *)&hb[(cur ^ 1) * HB + w * HB_Q + j * HB_J + 4 * q] = hn;
+        NTM_STAMP(4)   // ds_write + its completion
         __syncthreads();
+        NTM_STAMP(5)   // barrier
+    }
+    if constexpr (STAMP) {
+        if (a.dbg && l == 0)
+            for (int k = 0; k < 6; ++k) a.dbg[((size_t)blockIdx.x * 4 + w) * 6 + k] = seg[k];
     }
 
     __syncthreads();
@@ -337,13 +400,20 @@ hipError_t launch_gru_mfma(const GruArgs &a, hipStream_t stream)
     static_assert(MFMA_SMEM_FLOATS * sizeof(float) <= 96 * 1024, "LDS carve-up");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)gru_mfma_kernel,
+        hipError_t e = hipFuncSetAttribute((const void *)gru_mfma_kernel<false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const unsigned grid = (unsigned)((a.B + SG - 1) / SG);
-    hipLaunchKernelGGL(gru_mfma_kernel, dim3(grid), dim3(256), smem_bytes, stream, a);
+    if (a.dbg) {
+        hipError_t e = hipFuncSetAttribute((const void *)gru_mfma_kernel<true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(gru_mfma_kernel<true>, dim3(grid), dim3(256), smem_bytes, stream, a);
+    } else {
+        hipLaunchKernelGGL(gru_mfma_kernel<false>, dim3(grid), dim3(256), smem_bytes, stream, a);
+    }
     return hipGetLastError();
 }
 

@@ -1,0 +1,303 @@
+// GRU-HS[64] + head, MFMA variant 2 ("own quarter first, blocked issue"): the default K1 kernel.
+//
+// Same mapping as gru_mfma_kernel (16 streams per 4-wave workgroup, wave w owns hidden units
+// [16w,16w+16) of all three gates, W_hh resident in VGPRs as v_mfma_f32_16x16x4_f32 A-operands, exact
+// fp32), re-ordered around two measured facts (tools/ubench/*.hip, MI355X):
+//   (1) a VALU op issued between two f32 MFMAs of the SAME wave costs ~8 cycles of MFMA issue, a VALU op
+//       in a contiguous VALU block ~5: the f32 matrix pipe and the VALU do not overlap within a wave, so
+//       all 48 MFMAs of a step are issued back to back and the gate math follows as one block;
+//   (2) an LDS round trip (write -> barrier -> read) is ~200-300 cycles of pure latency.
+// Hence:
+//   * K permutation u(s,k) = 4s + k: K-step s consumes units 4s..4s+3, i.e. only the quarter of h that
+//     wave s>>2 produced.  A wave's four OWN K-steps need no LDS at all: its new h (C/D layout:
+//     lane (q,j) = stream j, units 16w+4q+v) becomes the B operands (lane (k,j) = unit 16w+4i+k for
+//     own K-step i) through a 4x4 transpose between lane group q and register index v, done with two
+//     v_permlane32_swap + two v_permlane16_swap.  The same transposed registers leave for the other
+//     waves as ONE ds_write_b128.
+//   * step t starts with 12 MFMAs (r,n,z x 4 own K-steps) straight out of registers; behind the third
+//     one sits the step's only barrier (all h_{t-1} writes are complete), then three ds_read_b128
+//     fetch the other three quarters while the remaining own MFMAs run; the other 36 MFMAs follow.
+//   * K-steps are numbered per wave (sigma = (s - 4w) mod 16) so that "own first" uses fixed registers.
+//   * the VALU block after the MFMAs: input terms of step t+1, the three gates on packed fp32 ops
+//     (v_pk_fma/add) and v_exp/v_rcp, the blend, the head partial of y_t over the lane's 4 units (the
+//     16 partials per sample are summed when a 64-sample tile is flushed), the transpose.
+//   * PRESCALE (default on): -log2(e) resp. 2 log2(e) are folded into W_hh / W_ih / biases when they
+//     are loaded, so sigmoid and tanh start directly with v_exp_f32 (saves 12 VALU ops per step).
+#include "ntm_common.h"
+
+namespace ntm {
+
+namespace m2 {
+constexpr int SG = 16;            // streams per workgroup
+constexpr int TT = 64;            // samples per x / y staging tile
+constexpr int HB_J = 20;          // floats per (k, stream) row: 16 K-steps + 4 pad (conflict-free b128)
+constexpr int HB_K = SG * HB_J;   // 320
+constexpr int HB = 4 * HB_K;      // 1280 floats per buffer
+constexpr int XS = TT + 1;
+constexpr int YP_Q = SG * XS;     // 1040 floats per partial plane
+constexpr int YP_N = 16;          // partial planes per tile buffer: (wave, lane group)
+constexpr int SMEM_FLOATS = 2 * HB + 2 * SG * XS + 2 * YP_N * YP_Q;
+}  // namespace m2
+
+__device__ __forceinline__ f32x4 mfma16x(float a, float b, f32x4 c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// 4x4 transpose between the wave's four 16-lane groups and four registers:
+// out[i] at lane group k  =  in[k] at lane group i   (same lane-in-group).
+__device__ __forceinline__ void transpose_groups4(float (&r)[4])
+{
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    unsigned a0 = __builtin_bit_cast(unsigned, r[0]), a1 = __builtin_bit_cast(unsigned, r[1]);
+    unsigned a2 = __builtin_bit_cast(unsigned, r[2]), a3 = __builtin_bit_cast(unsigned, r[3]);
+    // v_permlane32_swap X, Y : X[32..63] <-> Y[0..31]
+    u32x2 p = __builtin_amdgcn_permlane32_swap(a0, a2, false, false);
+    a0 = p[0]; a2 = p[1];
+    p = __builtin_amdgcn_permlane32_swap(a1, a3, false, false);
+    a1 = p[0]; a3 = p[1];
+    // v_permlane16_swap X, Y : X rows 1,3 <-> Y rows 0,2
+    p = __builtin_amdgcn_permlane16_swap(a0, a1, false, false);
+    a0 = p[0]; a1 = p[1];
+    p = __builtin_amdgcn_permlane16_swap(a2, a3, false, false);
+    a2 = p[0]; a3 = p[1];
+    r[0] = __builtin_bit_cast(float, a0); r[1] = __builtin_bit_cast(float, a1);
+    r[2] = __builtin_bit_cast(float, a2); r[3] = __builtin_bit_cast(float, a3);
+}
+
+__global__ __launch_bounds__(256) void debug_transpose_kernel(const float *in, float *out)
+{
+    float r[4];
+    for (int v = 0; v < 4; ++v) r[v] = in[threadIdx.x * 4 + v];
+    transpose_groups4(r);
+    for (int v = 0; v < 4; ++v) out[threadIdx.x * 4 + v] = r[v];
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool PRESCALE>
+__global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
+{
+    using namespace m2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *hb = smem;                  // [2][4 k][16 stream][20]
+    float *xb = hb + 2 * HB;           // [2][16][65]
+    float *yp = xb + 2 * SG * XS;      // [2][16 (w,q)][16][65]
+
+    const int tid = threadIdx.x;
+    const int l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = l >> 4, j = l & 15;  // q doubles as the K slot k of the A/B operand layouts
+    const int64_t s0 = (int64_t)blockIdx.x * SG;
+    const int64_t T = a.T;
+    const bool valid = (s0 + j) < a.B;
+    constexpr float LOG2E = 1.44269504088896340736f;
+    constexpr float SRZ = PRESCALE ? -LOG2E : 1.0f;        // scale of the r and z rows
+    constexpr float SN = PRESCALE ? 2.0f * LOG2E : 1.0f;   // scale of the n rows
+
+    // ---- resident operands ---------------------------------------------------------------
+    // A[sigma] = W_g[16w + (l&15)][4*((sigma+4w)&15) + (l>>4)]
+    float Ar[16], Az[16], An[16];
+    {
+        const int row = 16 * w + j;
+        const float *pr = a.w_hh + (size_t)(0 * kH + row) * kH + q;
+        const float *pz = a.w_hh + (size_t)(1 * kH + row) * kH + q;
+        const float *pn = a.w_hh + (size_t)(2 * kH + row) * kH + q;
+#pragma unroll
+        for (int sg = 0; sg < 16; ++sg) {
+            const int s = (sg + 4 * w) & 15;
+            Ar[sg] = pr[4 * s] * SRZ; Az[sg] = pz[4 * s] * SRZ; An[sg] = pn[4 * s] * SN;
+        }
+    }
+    // per-lane gate parameters of units 16w+4q+v, as packed pairs (v = 0,1 | 2,3)
+    f32x2 wir[2], wiz[2], win[2], br[2], bz[2], bin_[2], bhn[2], wo[2], hold[2];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int u = 16 * w + 4 * q + v;
+        wir[v >> 1][v & 1] = a.w_ih[u] * SRZ;
+        wiz[v >> 1][v & 1] = a.w_ih[kH + u] * SRZ;
+        win[v >> 1][v & 1] = a.w_ih[2 * kH + u] * SN;
+        br[v >> 1][v & 1] = (a.b_ih[u] + a.b_hh[u]) * SRZ;
+        bz[v >> 1][v & 1] = (a.b_ih[kH + u] + a.b_hh[kH + u]) * SRZ;
+        bin_[v >> 1][v & 1] = a.b_ih[2 * kH + u] * SN;
+        bhn[v >> 1][v & 1] = a.b_hh[2 * kH + u] * SN;
+        wo[v >> 1][v & 1] = a.w_o[u];
+        hold[v >> 1][v & 1] = (a.h_state && valid) ? a.h_state[(s0 + j) * kH + u] : 0.0f;
+    }
+    const float bo = a.b_o ? a.b_o[0] : 0.0f;
+
+    auto load_x_tile = [&](int64_t tile, float (&xr)[4]) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int e = tid + 256 * c;
+            const int64_t st = s0 + (e >> 6), tt = tile * TT + (e & 63);
+            xr[c] = (st < a.B && tt < T) ? a.x[st * a.xs + tt] : 0.0f;
+        }
+    };
+    auto store_x_tile = [&](int64_t tile, const float (&xr)[4]) {
+        float *dst = xb + (tile & 1) * SG * XS;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int e = tid + 256 * c;
+            dst[(e >> 6) * XS + (e & 63)] = xr[c];
+        }
+    };
+    auto flush_y_tile = [&](int64_t tile) {
+        const float *src = yp + (tile & 1) * YP_N * YP_Q;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int e = tid + 256 * c;
+            const int st = e >> 6, tt = e & 63;
+            float v = bo;
+#pragma unroll
+            for (int pl = 0; pl < YP_N; ++pl) v += src[pl * YP_Q + st * XS + tt];
+            const int64_t gs = s0 + st, gt = tile * TT + tt;
+            if (gs < a.B && gt < T) a.y[gs * a.ys + gt] = v;
+        }
+    };
+
+    float xr[4];
+    load_x_tile(0, xr);
+    store_x_tile(0, xr);
+    int64_t next_flush = 0;
+
+    // h_0: transpose into B-operand form, publish it, and prepare the input terms of step 0
+    float hT[4] = {hold[0][0], hold[0][1], hold[1][0], hold[1][1]};
+    transpose_groups4(hT);
+    *(f32x4 *)&hb[0 * HB + q * HB_K + j * HB_J + 4 * w] = (f32x4){hT[0], hT[1], hT[2], hT[3]};
+    __syncthreads();   // x tile 0 visible (the h_0 writes are covered by step 0's barrier as well)
+    f32x2 cr[2], cz[2], gi[2];
+    {
+        const float x0 = xb[j * XS];
+        const f32x2 xx = {x0, x0};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            cr[p] = __builtin_elementwise_fma(wir[p], xx, br[p]);
+            cz[p] = __builtin_elementwise_fma(wiz[p], xx, bz[p]);
+            gi[p] = __builtin_elementwise_fma(win[p], xx, bin_[p]);
+        }
+    }
+    float *const yp_lane = yp + (w * 4 + q) * YP_Q + j * XS;
+
+    for (int64_t t = 0; t < T; ++t) {
+        const int cur = (int)(t & 1);
+        const int ph = (int)(t & 63);
+        const int64_t tile = t >> 6;
+        float hB[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) hB[i] = hT[i];
+
+        // ---- the 48 MFMAs of the step, issued back to back: K-steps 0..3 (own quarter) come straight
+        //      from registers, the rest from the three ds_read_b128 issued behind the barrier ---------
+        f32x4 acc_r = {cr[0][0], cr[0][1], cr[1][0], cr[1][1]};
+        f32x4 acc_n = {bhn[0][0], bhn[0][1], bhn[1][0], bhn[1][1]};
+        f32x4 acc_z = {cz[0][0], cz[0][1], cz[1][0], cz[1][1]};
+        acc_r = mfma16x(Ar[0], hB[0], acc_r);
+        acc_n = mfma16x(An[0], hB[0], acc_n);
+        acc_z = mfma16x(Az[0], hB[0], acc_z);
+        // the step's only barrier: every wave's ds_write of h_{t-1} (issued at the end of its previous
+        // step) has completed; three MFMAs are already in the pipe.
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z)::"memory");
+        {
+            const float *rowp = hb + cur * HB + q * HB_K + j * HB_J;
+#pragma unroll
+            for (int c = 1; c < 4; ++c) {
+                const f32x4 v4 = *(const f32x4 *)(rowp + 4 * ((w + c) & 3));
+                hB[4 * c + 0] = v4.x; hB[4 * c + 1] = v4.y; hB[4 * c + 2] = v4.z; hB[4 * c + 3] = v4.w;
+            }
+        }
+        // x of step t+1 (its tile was staged at ph 34 of the previous tile at the latest)
+        const float xn = xb[(((t + 1) >> 6) & 1) * SG * XS + j * XS + (int)((t + 1) & 63)];
+#pragma unroll
+        for (int sg = 1; sg < 16; ++sg) {
+            acc_r = mfma16x(Ar[sg], hB[sg], acc_r);
+            acc_n = mfma16x(An[sg], hB[sg], acc_n);
+            acc_z = mfma16x(Az[sg], hB[sg], acc_z);
+            if (sg == 3) asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z));
+        }
+        asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z));
+
+        // tile housekeeping, once per 64 steps each (y partials of the previous tile are complete and
+        // visible once step 64i+65 has passed its barrier)
+        if (ph == 2) {
+            if (t > 65) { flush_y_tile(next_flush); ++next_flush; }
+            if ((tile + 1) * TT < T) load_x_tile(tile + 1, xr);
+        } else if (ph == 34) {
+            if ((tile + 1) * TT < T) store_x_tile(tile + 1, xr);
+        }
+
+        // ---- the VALU block ------------------------------------------------------------------------
+        // input terms of step t+1 first: they do not wait for the last MFMAs to drain
+        const f32x2 xx = {xn, xn};
+        f32x2 ncr[2], ncz[2], ngi[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            ncr[p] = __builtin_elementwise_fma(wir[p], xx, br[p]);
+            ncz[p] = __builtin_elementwise_fma(wiz[p], xx, bz[p]);
+            ngi[p] = __builtin_elementwise_fma(win[p], xx, bin_[p]);
+        }
+        const f32x2 one = {1.0f, 1.0f};
+        f32x2 hn[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            f32x2 ar = {acc_r[2 * p], acc_r[2 * p + 1]}, an = {acc_n[2 * p], acc_n[2 * p + 1]};
+            f32x2 az = {acc_z[2 * p], acc_z[2 * p + 1]};
+            if (!PRESCALE) { ar *= -LOG2E; az *= -LOG2E; }
+            f32x2 er = {__builtin_amdgcn_exp2f(ar[0]), __builtin_amdgcn_exp2f(ar[1])};
+            f32x2 ez = {__builtin_amdgcn_exp2f(az[0]), __builtin_amdgcn_exp2f(az[1])};
+            er += one; ez += one;
+            const f32x2 r = {__builtin_amdgcn_rcpf(er[0]), __builtin_amdgcn_rcpf(er[1])};
+            const f32x2 z = {__builtin_amdgcn_rcpf(ez[0]), __builtin_amdgcn_rcpf(ez[1])};
+            f32x2 pn = __builtin_elementwise_fma(r, an, gi[p]);        // (2 log2e) (gi_n + r gh_n) if PRESCALE
+            if (!PRESCALE) pn *= 2.0f * LOG2E;
+            f32x2 en = {__builtin_amdgcn_exp2f(pn[0]), __builtin_amdgcn_exp2f(pn[1])};
+            en += one;
+            const f32x2 rn = {__builtin_amdgcn_rcpf(en[0]), __builtin_amdgcn_rcpf(en[1])};
+            const f32x2 n = __builtin_elementwise_fma((f32x2){-2.0f, -2.0f}, rn, one);   // tanh
+            hn[p] = __builtin_elementwise_fma(z, hold[p] - n, n);                         // n + z (h - n)
+        }
+        // head partial of y_t over this lane's four units; publish
+        {
+            const f32x2 pp = __builtin_elementwise_fma(hn[1], wo[1], hn[0] * wo[0]);
+            yp_lane[(tile & 1) * YP_N * YP_Q + ph] = pp[0] + pp[1];
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { hold[p] = hn[p]; cr[p] = ncr[p]; cz[p] = ncz[p]; gi[p] = ngi[p]; }
+        hT[0] = hn[0][0]; hT[1] = hn[0][1]; hT[2] = hn[1][0]; hT[3] = hn[1][1];
+        transpose_groups4(hT);
+        *(f32x4 *)&hb[(cur ^ 1) * HB + q * HB_K + j * HB_J + 4 * w] = (f32x4){hT[0], hT[1], hT[2], hT[3]};
+    }
+
+    // ---- epilogue: remaining y tiles, final state ---------------------------------------------------
+    __syncthreads();
+    while (next_flush * TT < T) { flush_y_tile(next_flush); ++next_flush; }
+
+    if (a.h_state && valid) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) a.h_state[(s0 + j) * kH + 16 * w + 4 * q + v] = hold[v >> 1][v & 1];
+    }
+}
+
+hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream)
+{
+    static const size_t smem_bytes = m2::SMEM_FLOATS * sizeof(float);   // 151 680 B: one workgroup per CU
+    static_assert(m2::SMEM_FLOATS * sizeof(float) <= 160 * 1024, "LDS carve-up");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)gru_mfma2_kernel<true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const unsigned grid = (unsigned)((a.B + m2::SG - 1) / m2::SG);
+    hipLaunchKernelGGL(gru_mfma2_kernel<true>, dim3(grid), dim3(256), smem_bytes, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_debug_transpose(const float *in, float *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(debug_transpose_kernel, dim3(1), dim3(256), 0, stream, in, out);
+    return hipGetLastError();
+}
+
+}  // namespace ntm

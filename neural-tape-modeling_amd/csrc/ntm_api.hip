@@ -44,12 +44,13 @@ int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, 
     if (B == 0 || T == 0) return NTM_OK;
     if (!w_ih || !w_hh || !b_ih || !b_hh || !w_o || !x || !y) return fail(NTM_EINVAL, "ntm_gru_forward: null pointer");
     if (x_stride_b < T || y_stride_b < T) return fail(NTM_EINVAL, "ntm_gru_forward: stride < T");
-    ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, x_stride_b, y_stride_b};
+    ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, x_stride_b, y_stride_b, nullptr};
     if (variant == NTM_GRU_AUTO) variant = NTM_GRU_MFMA;
     hipError_t e;
     switch (variant) {
         case NTM_GRU_MFMA: e = ntm::launch_gru_mfma(a, (hipStream_t)stream); break;
         case NTM_GRU_VALU: e = ntm::launch_gru_valu(a, (hipStream_t)stream); break;
+        case NTM_GRU_MFMA2: e = ntm::launch_gru_mfma2(a, (hipStream_t)stream); break;
         default: return fail(NTM_EINVAL, "ntm_gru_forward: unknown kernel variant");
     }
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_gru_forward");
@@ -61,6 +62,23 @@ int ntm_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih, con
 {
     return ntm_gru_forward_ex(w_ih, w_hh, b_ih, b_hh, w_o, b_o, H, x, y, B, T, x_stride_b, y_stride_b, h_state,
                               NTM_GRU_AUTO, stream);
+}
+
+int ntm_debug_gru_stamps(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *w_o,
+                         const float *b_o, const float *x, float *y, int64_t B, int64_t T, float *h_state,
+                         uint64_t *stamps, void *stream)
+{
+    if (!stamps || !x || !y || B <= 0 || T <= 0) return fail(NTM_EINVAL, "ntm_debug_gru_stamps: bad argument");
+    ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, T, T, (unsigned long long *)stamps};
+    hipError_t e = ntm::launch_gru_mfma(a, (hipStream_t)stream);
+    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_debug_gru_stamps");
+}
+
+int ntm_debug_transpose4(const float *in, float *out, void *stream)
+{
+    if (!in || !out) return fail(NTM_EINVAL, "ntm_debug_transpose4: null pointer");
+    hipError_t e = ntm::launch_debug_transpose(in, out, (hipStream_t)stream);
+    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_debug_transpose4");
 }
 
 int64_t ntm_delay_scratch_floats(int64_t B, int64_t T, int D)

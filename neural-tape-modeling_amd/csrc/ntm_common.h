@@ -31,6 +31,7 @@ struct GruArgs {
     float *y;
     float *h_state;  // [B,64] in/out, may be null
     int64_t B, T, xs, ys;
+    unsigned long long *dbg;  // diagnostic stamp sums (ntm_debug_gru_stamps), else null
 };
 
 }  // namespace ntm
@@ -38,4 +39,6 @@ struct GruArgs {
 namespace ntm {
 hipError_t launch_gru_mfma(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_valu(const GruArgs &a, hipStream_t stream);
+hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream);
+hipError_t launch_debug_transpose(const float *in, float *out, hipStream_t stream);
 }  // namespace ntm

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 W_G = "GRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE]_BEST"
 W_D = "DiffDelGRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE_WOWFLUTTER]_BEST"
-VARIANTS = ["mfma", "valu"]
+VARIANTS = ["mfma2", "mfma", "valu"]
 
 
 @pytest.fixture(scope="module")
@@ -46,6 +46,20 @@ def make_ddr(ntm, max_delay, name=W_D, variant="auto"):
     m = m.to("cuda").eval()
     m.kernel_variant = variant
     return m
+
+
+def test_lane_group_transpose(ntm):
+    """The in-register 4x4 transpose of the MFMA2 kernel (v_permlane32_swap / v_permlane16_swap):
+    out[i] at lane group k == in[k] at lane group i, per wave, same lane-in-group."""
+    L = ntm._lib.lib()
+    a = np.arange(256 * 4, dtype=np.float32).reshape(4, 4, 16, 4)        # [wave][group][lane][reg]
+    x = dev(a.reshape(256, 4))
+    out = torch.empty_like(x)
+    assert L.ntm_debug_transpose4(ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(out.data_ptr()), None) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(4, 4, 16, 4)
+    want = a.transpose(0, 3, 2, 1)                                        # swap group <-> reg
+    assert np.array_equal(got, want)
 
 
 # ----------------------------------------------------------------------------- GRU vs goldens
@@ -132,7 +146,7 @@ def test_variants_agree_and_raw_abi_strides(ntm):
     xh = rng.uniform(-0.5, 0.5, (B, XS)).astype(np.float32)
     x = dev(xh)
     outs = []
-    for variant in (1, 2):
+    for variant in (1, 2, 3):
         y = torch.full((B, YS), 7.0, device="cuda")
         rc = L.ntm_gru_forward_ex(*[ctypes.c_void_p(sd[k].data_ptr()) for k in
                                     ["GRU.weight_ih_l0", "GRU.weight_hh_l0", "GRU.bias_ih_l0", "GRU.bias_hh_l0",
@@ -145,8 +159,9 @@ def test_variants_agree_and_raw_abi_strides(ntm):
         assert np.all(yh[:, T:] == 7.0)                       # nothing written past T
         outs.append(yh[:, :T])
     yo, _ = oracle.gru_forward(oracle_weights(W_G), xh[:, :T])
-    assert np.abs(outs[0] - yo).max() < TOL and np.abs(outs[1] - yo).max() < TOL
-    assert np.abs(outs[0] - outs[1]).max() < 2e-6
+    for o in outs:
+        assert np.abs(o - yo).max() < TOL
+        assert np.abs(o - outs[0]).max() < 2e-6
 
 
 def test_abi_errors(ntm):

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Diagnostic: where does one GRU step spend its cycles? (s_memtime stamps, MFMA kernel)"""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import ntm_amd
+from ntm_amd._lib import ptr
+B, T = 4096, 4096
+m = ntm_amd.harness.build_model(ntm_amd.weights.W_GRU)
+x = torch.rand(B, T, device="cuda") - 0.5
+y = torch.empty_like(x); h = torch.zeros(B, 64, device="cuda")
+st = torch.zeros((B + 15) // 16, 4, 6, dtype=torch.int64, device="cuda")
+g, o = m.GRU, m.output
+L = ntm_amd._lib.lib()
+for _ in range(2):
+    rc = L.ntm_debug_gru_stamps(ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0),
+                                ptr(o.weight), ptr(o.bias), ptr(x), ptr(y), B, T, ptr(h), ptr(st), None)
+    assert rc == 0, L.ntm_last_error()
+    torch.cuda.synchronize()
+s = st.cpu().numpy().astype(np.float64) / T
+names = ["lds_read", "phaseA", "phaseB", "tail", "lds_write", "barrier"]
+print("cycles per step (s_memtime ticks = shader cycles... 100 MHz ticks if memrealtime); mean over workgroups")
+for w in range(4):
+    print(f"wave {w}: " + "  ".join(f"{n}={s[:, w, k].mean():8.1f}" for k, n in enumerate(names)) + f"  total={s[:, w, :].sum(1).mean():8.1f}")
