@@ -70,13 +70,21 @@ int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, 
                        float *h_state, int variant, void *stream);
 
 /*
- * DIAGNOSTIC ONLY (never timed): the MFMA kernel with s_memtime stamps.  stamps[(B+15)/16][4][6]
- * (device, uint64) receives per-wave cycle sums of  LDS read | phase A | phase B | tail | LDS
- * write | barrier  over the whole launch.  Outputs are the same as ntm_gru_forward.
+ * DIAGNOSTIC ONLY (never timed): an MFMA kernel (variant NTM_GRU_MFMA or NTM_GRU_MFMA2) with
+ * s_memtime stamps.  stamps[(B+15)/16][4][6] (device, uint64) receives per-wave cycle sums of six
+ * step segments over the whole launch (segment names: tools/stamp_profile.py).  Outputs are the
+ * same as ntm_gru_forward.
  */
 int ntm_debug_gru_stamps(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
                          const float *w_o, const float *b_o, const float *x, float *y, int64_t B,
-                         int64_t T, float *h_state, uint64_t *stamps, void *stream);
+                         int64_t T, float *h_state, uint64_t *stamps, int variant, void *stream);
+
+/* DIAGNOSTIC ONLY (wrong results on purpose, for timing ablations of the MFMA2 kernel): mask bits
+ * 1 no gate math, 2 no LDS exchange of h, 4 no head partial, 8 own-quarter MFMAs only, 16 no barrier,
+ * 32 no tile housekeeping; only the combinations compiled in gru_mfma2.hip are accepted. */
+int ntm_debug_gru_ablate(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                         const float *w_o, const float *b_o, const float *x, float *y, int64_t B,
+                         int64_t T, float *h_state, int mask, void *stream);
 
 /* DIAGNOSTIC ONLY: the in-register 4x4 lane-group transpose used by the MFMA2 kernel, applied to one
  * 256-thread block: in/out [256][4] floats (device). */

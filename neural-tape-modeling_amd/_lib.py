@@ -22,8 +22,9 @@ _SIGNATURES = {
     "ntm_last_error": (ctypes.c_char_p, []),
     "ntm_gru_forward": (_int, [_vp] * 6 + [_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "ntm_gru_forward_ex": (_int, [_vp] * 6 + [_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp]),
-    "ntm_debug_gru_stamps": (_int, [_vp] * 6 + [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "ntm_debug_gru_stamps": (_int, [_vp] * 6 + [_vp, _vp, _i64, _i64, _vp, _vp, _int, _vp]),
     "ntm_debug_transpose4": (_int, [_vp, _vp, _vp]),
+    "ntm_debug_gru_ablate": (_int, [_vp] * 6 + [_vp, _vp, _i64, _i64, _vp, _int, _vp]),
     "ntm_delay_forward": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _int, _int, _vp, _vp, _vp]),
     "ntm_delay_scratch_floats": (_i64, [_i64, _i64, _int]),
     "ntm_diffdel_gru_forward": (_int, [_vp] * 5 + [_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _int,

@@ -8,12 +8,13 @@
 //       all 48 MFMAs of a step are issued back to back and the gate math follows as one block;
 //   (2) an LDS round trip (write -> barrier -> read) is ~200-300 cycles of pure latency.
 // Hence:
-//   * K permutation u(s,k) = 4s + k: K-step s consumes units 4s..4s+3, i.e. only the quarter of h that
-//     wave s>>2 produced.  A wave's four OWN K-steps need no LDS at all: its new h (C/D layout:
-//     lane (q,j) = stream j, units 16w+4q+v) becomes the B operands (lane (k,j) = unit 16w+4i+k for
-//     own K-step i) through a 4x4 transpose between lane group q and register index v, done with two
-//     v_permlane32_swap + two v_permlane16_swap.  The same transposed registers leave for the other
-//     waves as ONE ds_write_b128.
+//   * K permutation unit(s,k) = 16(s>>2) + 4k + (s&3): K-step s consumes only units of the quarter of h
+//     that wave s>>2 produced, and for a wave's four OWN K-steps (s = 4w+v) the B operand of lane
+//     (k,j) is unit 16w+4k+v of stream j -- exactly register v of the C/D fragment the same lane just
+//     produced (C/D layout: lane (q,j) = stream j, units 16w+4q+v).  So the new h feeds the next
+//     step's first 12 MFMAs with no data movement at all, and leaves for the other three waves as ONE
+//     ds_write_b128 of those same registers.  (transpose_groups4 below is kept for the unit test of
+//     the permlane-swap idiom; the kernel no longer needs it.)
 //   * step t starts with 12 MFMAs (r,n,z x 4 own K-steps) straight out of registers; behind the third
 //     one sits the step's only barrier (all h_{t-1} writes are complete), then three ds_read_b128
 //     fetch the other three quarters while the remaining own MFMAs run; the other 36 MFMAs follow.
@@ -33,10 +34,12 @@ constexpr int TT = 64;            // samples per x / y staging tile
 constexpr int HB_J = 20;          // floats per (k, stream) row: 16 K-steps + 4 pad (conflict-free b128)
 constexpr int HB_K = SG * HB_J;   // 320
 constexpr int HB = 4 * HB_K;      // 1280 floats per buffer
-constexpr int XS = TT + 1;
-constexpr int YP_Q = SG * XS;     // 1040 floats per partial plane
+constexpr int XS = TT + 1;        // x tile row (conflict-free column reads)
+constexpr int YS = TT + 4;        // y partial row: 16-B aligned rows for ds_read_b128 at flush
+constexpr int YP_Q = SG * YS;     // 1088 floats per partial plane
 constexpr int YP_N = 16;          // partial planes per tile buffer: (wave, lane group)
 constexpr int SMEM_FLOATS = 2 * HB + 2 * SG * XS + 2 * YP_N * YP_Q;
+static_assert((2 * HB + 2 * SG * XS) % 4 == 0 && YS % 4 == 0 && YP_Q % 4 == 0, "y partial rows must be 16-B aligned");
 }  // namespace m2
 
 __device__ __forceinline__ f32x4 mfma16x(float a, float b, f32x4 c)
@@ -75,14 +78,29 @@ __global__ __launch_bounds__(256) void debug_transpose_kernel(const float *in, f
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <bool PRESCALE>
+#define NTM2_STAMP(k)                                                                       \
+    if constexpr (STAMP) {                                                                  \
+        unsigned long long now_;                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                  \
+        seg[k] += now_ - last_;                                                             \
+        last_ = now_;                                                                       \
+    }
+
+// ABL != 0 are DIAGNOSTIC instantiations (wrong results on purpose, never timed as product):
+//   1 no gate math   2 no LDS exchange of h (barrier kept)   4 no head partial   8 no MFMAs on the
+//   other quarters   16 no barrier   32 no tile housekeeping
+template <bool PRESCALE, bool STAMP, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 {
     using namespace m2;
+    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, last_ = 0;
+    (void)seg; (void)last_;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *hb = smem;                  // [2][4 k][16 stream][20]
     float *xb = hb + 2 * HB;           // [2][16][65]
-    float *yp = xb + 2 * SG * XS;      // [2][16 (w,q)][16][65]
+    float *yp = xb + 2 * SG * XS;      // [2][16 (w,q)][16][68]   (offset 4640 floats: 16-B aligned)
 
     const int tid = threadIdx.x;
     const int l = tid & 63;
@@ -96,17 +114,18 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     constexpr float SN = PRESCALE ? 2.0f * LOG2E : 1.0f;   // scale of the n rows
 
     // ---- resident operands ---------------------------------------------------------------
-    // A[sigma] = W_g[16w + (l&15)][4*((sigma+4w)&15) + (l>>4)]
+    // A[sigma] = W_g[16w + (l&15)][unit(s, l>>4)],  s = (sigma + 4w) & 15,  unit(s,k) = 16(s>>2) + 4k + (s&3)
     float Ar[16], Az[16], An[16];
     {
         const int row = 16 * w + j;
-        const float *pr = a.w_hh + (size_t)(0 * kH + row) * kH + q;
-        const float *pz = a.w_hh + (size_t)(1 * kH + row) * kH + q;
-        const float *pn = a.w_hh + (size_t)(2 * kH + row) * kH + q;
+        const float *pr = a.w_hh + (size_t)(0 * kH + row) * kH + 4 * q;
+        const float *pz = a.w_hh + (size_t)(1 * kH + row) * kH + 4 * q;
+        const float *pn = a.w_hh + (size_t)(2 * kH + row) * kH + 4 * q;
 #pragma unroll
         for (int sg = 0; sg < 16; ++sg) {
             const int s = (sg + 4 * w) & 15;
-            Ar[sg] = pr[4 * s] * SRZ; Az[sg] = pz[4 * s] * SRZ; An[sg] = pn[4 * s] * SN;
+            const int u0 = 16 * (s >> 2) + (s & 3);
+            Ar[sg] = pr[u0] * SRZ; Az[sg] = pz[u0] * SRZ; An[sg] = pn[u0] * SN;
         }
     }
     // per-lane gate parameters of units 16w+4q+v, as packed pairs (v = 0,1 | 2,3)
@@ -142,17 +161,24 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
             dst[(e >> 6) * XS + (e & 63)] = xr[c];
         }
     };
+    // y tile flush: thread -> stream tid>>4, samples 4*(tid&15)..+3; the 16 partial planes (wave, lane
+    // group) are summed in a fixed order (deterministic), one ds_read_b128 per plane.
+    const bool y_vec_ok = ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) && ((a.ys & 3) == 0);
     auto flush_y_tile = [&](int64_t tile) {
-        const float *src = yp + (tile & 1) * YP_N * YP_Q;
+        const float *src = yp + (tile & 1) * YP_N * YP_Q + (tid >> 4) * YS + 4 * (tid & 15);
+        f32x4 v = {bo, bo, bo, bo};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int e = tid + 256 * c;
-            const int st = e >> 6, tt = e & 63;
-            float v = bo;
+        for (int pl = 0; pl < YP_N; ++pl) v += *(const f32x4 *)(src + pl * YP_Q);
+        const int64_t gs = s0 + (tid >> 4), gt = tile * TT + 4 * (tid & 15);
+        if (gs < a.B) {
+            float *dst = a.y + gs * a.ys + gt;
+            if (y_vec_ok && gt + 3 < T) {
+                *(f32x4 *)dst = v;
+            } else {
 #pragma unroll
-            for (int pl = 0; pl < YP_N; ++pl) v += src[pl * YP_Q + st * XS + tt];
-            const int64_t gs = s0 + st, gt = tile * TT + tt;
-            if (gs < a.B && gt < T) a.y[gs * a.ys + gt] = v;
+                for (int c = 0; c < 4; ++c)
+                    if (gt + c < T) dst[c] = v[c];
+            }
         }
     };
 
@@ -161,9 +187,8 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     store_x_tile(0, xr);
     int64_t next_flush = 0;
 
-    // h_0: transpose into B-operand form, publish it, and prepare the input terms of step 0
+    // h_0: already in B-operand form for the own K-steps; publish it, prepare the input terms of step 0
     float hT[4] = {hold[0][0], hold[0][1], hold[1][0], hold[1][1]};
-    transpose_groups4(hT);
     *(f32x4 *)&hb[0 * HB + q * HB_K + j * HB_J + 4 * w] = (f32x4){hT[0], hT[1], hT[2], hT[3]};
     __syncthreads();   // x tile 0 visible (the h_0 writes are covered by step 0's barrier as well)
     f32x2 cr[2], cz[2], gi[2];
@@ -177,8 +202,9 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
             gi[p] = __builtin_elementwise_fma(win[p], xx, bin_[p]);
         }
     }
-    float *const yp_lane = yp + (w * 4 + q) * YP_Q + j * XS;
+    float *const yp_lane = yp + (w * 4 + q) * YP_Q + j * YS;
 
+    if constexpr (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
     for (int64_t t = 0; t < T; ++t) {
         const int cur = (int)(t & 1);
         const int ph = (int)(t & 63);
@@ -195,10 +221,15 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         acc_r = mfma16x(Ar[0], hB[0], acc_r);
         acc_n = mfma16x(An[0], hB[0], acc_n);
         acc_z = mfma16x(Az[0], hB[0], acc_z);
-        // the step's only barrier: every wave's ds_write of h_{t-1} (issued at the end of its previous
-        // step) has completed; three MFMAs are already in the pipe.
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z)::"memory");
-        {
+        // the step's only barrier: every wave's ds_write_b128 of h_{t-1} has completed (lgkmcnt(1): LDS
+        // ops retire in order and the only younger one is the y partial write, which may stay in
+        // flight -- its readers are two barriers away); three MFMAs are already in the pipe.
+        if constexpr (ABL & 16) asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z)::"memory");
+        else asm volatile("s_waitcnt lgkmcnt(1)\n\ts_barrier" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z)::"memory");
+        if constexpr (ABL & 2) {
+#pragma unroll
+            for (int i = 4; i < 16; ++i) hB[i] = hT[i & 3];
+        } else {
             const float *rowp = hb + cur * HB + q * HB_K + j * HB_J;
 #pragma unroll
             for (int c = 1; c < 4; ++c) {
@@ -209,17 +240,19 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         // x of step t+1 (its tile was staged at ph 34 of the previous tile at the latest)
         const float xn = xb[(((t + 1) >> 6) & 1) * SG * XS + j * XS + (int)((t + 1) & 63)];
 #pragma unroll
-        for (int sg = 1; sg < 16; ++sg) {
+        for (int sg = 1; sg < ((ABL & 8) ? 4 : 16); ++sg) {
             acc_r = mfma16x(Ar[sg], hB[sg], acc_r);
             acc_n = mfma16x(An[sg], hB[sg], acc_n);
             acc_z = mfma16x(Az[sg], hB[sg], acc_z);
             if (sg == 3) asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z));
         }
         asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z));
+        NTM2_STAMP(0)   // barrier + LDS reads + issue of the 48 MFMAs
 
         // tile housekeeping, once per 64 steps each (y partials of the previous tile are complete and
         // visible once step 64i+65 has passed its barrier)
-        if (ph == 2) {
+        if constexpr (ABL & 32) {
+        } else if (ph == 2) {
             if (t > 65) { flush_y_tile(next_flush); ++next_flush; }
             if ((tile + 1) * TT < T) load_x_tile(tile + 1, xr);
         } else if (ph == 34) {
@@ -236,12 +269,17 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
             ncz[p] = __builtin_elementwise_fma(wiz[p], xx, bz[p]);
             ngi[p] = __builtin_elementwise_fma(win[p], xx, bin_[p]);
         }
+        // (pinned ahead of the gates: they fill the ~40 cycles the last MFMAs need to drain)
+        asm volatile("" : "+v"(ncr[0]), "+v"(ncr[1]), "+v"(ncz[0]), "+v"(ncz[1]), "+v"(ngi[0]), "+v"(ngi[1]),
+                          "+v"(acc_r), "+v"(acc_n), "+v"(acc_z));
+        NTM2_STAMP(1)   // housekeeping + input terms of step t+1
         const f32x2 one = {1.0f, 1.0f};
         f32x2 hn[2];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             f32x2 ar = {acc_r[2 * p], acc_r[2 * p + 1]}, an = {acc_n[2 * p], acc_n[2 * p + 1]};
             f32x2 az = {acc_z[2 * p], acc_z[2 * p + 1]};
+            if constexpr (ABL & 1) { hn[p] = (ar + an) + (az + gi[p]); continue; }
             if (!PRESCALE) { ar *= -LOG2E; az *= -LOG2E; }
             f32x2 er = {__builtin_amdgcn_exp2f(ar[0]), __builtin_amdgcn_exp2f(ar[1])};
             f32x2 ez = {__builtin_amdgcn_exp2f(az[0]), __builtin_amdgcn_exp2f(az[1])};
@@ -256,16 +294,29 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
             const f32x2 n = __builtin_elementwise_fma((f32x2){-2.0f, -2.0f}, rn, one);   // tanh
             hn[p] = __builtin_elementwise_fma(z, hold[p] - n, n);                         // n + z (h - n)
         }
-        // head partial of y_t over this lane's four units; publish
-        {
-            const f32x2 pp = __builtin_elementwise_fma(hn[1], wo[1], hn[0] * wo[0]);
-            yp_lane[(tile & 1) * YP_N * YP_Q + ph] = pp[0] + pp[1];
-        }
+        asm volatile("" : "+v"(hn[0]), "+v"(hn[1]));
+        NTM2_STAMP(2)   // gates (includes draining the last MFMAs)
+        // publish h_t first (it is on the critical path of every wave's next step) ...
 #pragma unroll
         for (int p = 0; p < 2; ++p) { hold[p] = hn[p]; cr[p] = ncr[p]; cz[p] = ncz[p]; gi[p] = ngi[p]; }
         hT[0] = hn[0][0]; hT[1] = hn[0][1]; hT[2] = hn[1][0]; hT[3] = hn[1][1];
-        transpose_groups4(hT);
-        *(f32x4 *)&hb[(cur ^ 1) * HB + q * HB_K + j * HB_J + 4 * w] = (f32x4){hT[0], hT[1], hT[2], hT[3]};
+        NTM2_STAMP(3)
+        if constexpr (!(ABL & 2))
+            *(f32x4 *)&hb[(cur ^ 1) * HB + q * HB_K + j * HB_J + 4 * w] = (f32x4){hT[0], hT[1], hT[2], hT[3]};
+        asm volatile("" ::: "memory");   // keep the two LDS writes in this order (see the barrier's lgkmcnt)
+        NTM2_STAMP(4)   // ds_write_b128 (+ completion, stamped build only)
+        // ... then the head partial of y_t over this lane's four units
+        if constexpr (!(ABL & 4)) {
+            const f32x2 pp = __builtin_elementwise_fma(hn[1], wo[1], hn[0] * wo[0]);
+            yp_lane[(tile & 1) * YP_N * YP_Q + ph] = pp[0] + pp[1];
+        } else {
+            yp_lane[0] = 0.0f;           // keep the LDS-op count the barrier's lgkmcnt(1) relies on
+        }
+        NTM2_STAMP(5)   // head partial + its ds_write
+    }
+    if constexpr (STAMP) {
+        if (a.dbg && l == 0)
+            for (int k = 0; k < 6; ++k) a.dbg[((size_t)blockIdx.x * 4 + w) * 6 + k] = seg[k];
     }
 
     // ---- epilogue: remaining y tiles, final state ---------------------------------------------------
@@ -284,13 +335,33 @@ hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream)
     static_assert(m2::SMEM_FLOATS * sizeof(float) <= 160 * 1024, "LDS carve-up");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)gru_mfma2_kernel<true>,
+        hipError_t e = hipFuncSetAttribute((const void *)gru_mfma2_kernel<true, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const unsigned grid = (unsigned)((a.B + m2::SG - 1) / m2::SG);
-    hipLaunchKernelGGL(gru_mfma2_kernel<true>, dim3(grid), dim3(256), smem_bytes, stream, a);
+#define NTM2_ABL_CASE(M)                                                                                   \
+    case M: {                                                                                              \
+        hipError_t e = hipFuncSetAttribute((const void *)gru_mfma2_kernel<true, false, M>,                 \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);   \
+        if (e != hipSuccess) return e;                                                                     \
+        hipLaunchKernelGGL((gru_mfma2_kernel<true, false, M>), dim3(grid), dim3(256), smem_bytes, stream, a); \
+        return hipGetLastError();                                                                          \
+    }
+    switch (a.abl) {
+        NTM2_ABL_CASE(1) NTM2_ABL_CASE(2) NTM2_ABL_CASE(4) NTM2_ABL_CASE(8) NTM2_ABL_CASE(16) NTM2_ABL_CASE(32)
+        NTM2_ABL_CASE(3) NTM2_ABL_CASE(7) NTM2_ABL_CASE(18) NTM2_ABL_CASE(39) NTM2_ABL_CASE(55) NTM2_ABL_CASE(63)
+        default: break;
+    }
+    if (a.dbg) {
+        hipError_t e = hipFuncSetAttribute((const void *)gru_mfma2_kernel<true, true>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((gru_mfma2_kernel<true, true>), dim3(grid), dim3(256), smem_bytes, stream, a);
+    } else {
+        hipLaunchKernelGGL((gru_mfma2_kernel<true, false>), dim3(grid), dim3(256), smem_bytes, stream, a);
+    }
     return hipGetLastError();
 }
 

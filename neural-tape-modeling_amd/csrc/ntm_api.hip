@@ -44,7 +44,7 @@ int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, 
     if (B == 0 || T == 0) return NTM_OK;
     if (!w_ih || !w_hh || !b_ih || !b_hh || !w_o || !x || !y) return fail(NTM_EINVAL, "ntm_gru_forward: null pointer");
     if (x_stride_b < T || y_stride_b < T) return fail(NTM_EINVAL, "ntm_gru_forward: stride < T");
-    ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, x_stride_b, y_stride_b, nullptr};
+    ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, x_stride_b, y_stride_b, nullptr, 0};
     if (variant == NTM_GRU_AUTO) variant = NTM_GRU_MFMA;
     hipError_t e;
     switch (variant) {
@@ -66,12 +66,23 @@ int ntm_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih, con
 
 int ntm_debug_gru_stamps(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *w_o,
                          const float *b_o, const float *x, float *y, int64_t B, int64_t T, float *h_state,
-                         uint64_t *stamps, void *stream)
+                         uint64_t *stamps, int variant, void *stream)
 {
     if (!stamps || !x || !y || B <= 0 || T <= 0) return fail(NTM_EINVAL, "ntm_debug_gru_stamps: bad argument");
-    ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, T, T, (unsigned long long *)stamps};
-    hipError_t e = ntm::launch_gru_mfma(a, (hipStream_t)stream);
+    ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, T, T, (unsigned long long *)stamps, 0};
+    hipError_t e = variant == NTM_GRU_MFMA ? ntm::launch_gru_mfma(a, (hipStream_t)stream)
+                                           : ntm::launch_gru_mfma2(a, (hipStream_t)stream);
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_debug_gru_stamps");
+}
+
+int ntm_debug_gru_ablate(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *w_o,
+                         const float *b_o, const float *x, float *y, int64_t B, int64_t T, float *h_state, int mask,
+                         void *stream)
+{
+    if (!x || !y || B <= 0 || T <= 0 || mask <= 0) return fail(NTM_EINVAL, "ntm_debug_gru_ablate: bad argument");
+    ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, T, T, nullptr, mask};
+    hipError_t e = ntm::launch_gru_mfma2(a, (hipStream_t)stream);
+    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_debug_gru_ablate");
 }
 
 int ntm_debug_transpose4(const float *in, float *out, void *stream)

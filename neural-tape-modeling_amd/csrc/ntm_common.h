@@ -32,6 +32,7 @@ struct GruArgs {
     float *h_state;  // [B,64] in/out, may be null
     int64_t B, T, xs, ys;
     unsigned long long *dbg;  // diagnostic stamp sums (ntm_debug_gru_stamps), else null
+    int abl;                  // diagnostic ablation mask (ntm_debug_gru_ablate), else 0
 };
 
 }  // namespace ntm

@@ -13,13 +13,16 @@ y = torch.empty_like(x); h = torch.zeros(B, 64, device="cuda")
 st = torch.zeros((B + 15) // 16, 4, 6, dtype=torch.int64, device="cuda")
 g, o = m.GRU, m.output
 L = ntm_amd._lib.lib()
-for _ in range(2):
-    rc = L.ntm_debug_gru_stamps(ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0),
-                                ptr(o.weight), ptr(o.bias), ptr(x), ptr(y), B, T, ptr(h), ptr(st), None)
-    assert rc == 0, L.ntm_last_error()
-    torch.cuda.synchronize()
-s = st.cpu().numpy().astype(np.float64) / T
-names = ["lds_read", "phaseA", "phaseB", "tail", "lds_write", "barrier"]
-print("cycles per step (s_memtime ticks = shader cycles... 100 MHz ticks if memrealtime); mean over workgroups")
-for w in range(4):
-    print(f"wave {w}: " + "  ".join(f"{n}={s[:, w, k].mean():8.1f}" for k, n in enumerate(names)) + f"  total={s[:, w, :].sum(1).mean():8.1f}")
+NAMES = {1: ["lds_read", "phaseA", "phaseB", "tail", "lds_write", "barrier"],
+         3: ["bar+48mfma", "hk+cinit", "gates", "head", "transpose", "ds_write"]}
+for variant in (3, 1):
+    for _ in range(2):
+        rc = L.ntm_debug_gru_stamps(ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0),
+                                    ptr(o.weight), ptr(o.bias), ptr(x), ptr(y), B, T, ptr(h), ptr(st), variant, None)
+        assert rc == 0, L.ntm_last_error()
+        torch.cuda.synchronize()
+    s = st.cpu().numpy().astype(np.float64) / T
+    print(f"variant {variant}: s_memtime cycles per step, mean over workgroups (stamped build; shares, not totals)")
+    for w in range(4):
+        print(f"  wave {w}: " + "  ".join(f"{n}={s[:, w, k].mean():7.1f}" for k, n in enumerate(NAMES[variant]))
+              + f"  total={s[:, w, :].sum(1).mean():7.1f}")
