@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="segments per GPU")
     ap.add_argument("--samples", type=int, default=65536, help="samples per segment")
-    ap.add_argument("--variant", default="auto", choices=["auto", "mfma", "valu"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "mfma2", "mfma", "valu"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -173,6 +173,14 @@ def main():
         checks["stream0_vs_reference_max_abs"] = float(np.abs(e).max())
         checks["stream0_vs_reference_esr"] = float((e[INIT_LEN:] ** 2).mean() /
                                                    ((gold["y"][0, 0][INIT_LEN:] ** 2).mean() + ESR_EPS))
+    # HBM bytes per launch from the PMC counters (collected in separate rocprofv3 --pmc passes, gfx950
+    # FETCH_SIZE correction applied; see profiles/*pmc_traffic*.json) -- only for the matching workload
+    traffic = None
+    if (B, T) == (4096, 65536) and a.variant in ("auto", "mfma2"):
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic_mfma2*.json")))
+        if files:
+            traffic = json.load(open(files[-1]))["hbm_bytes_per_launch_corrected"]
     out = {
         "metric": "audio samples/sec (44.1 kHz) GRU-HS[64], batch=4096x65536",
         "value": total_samples / elapsed, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
@@ -184,8 +192,9 @@ def main():
                    "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
         "realtime_factor": total_samples / elapsed / FS,
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": tflops / PEAK_FP32_TFLOPS, "traffic": None,
-                     "kernel": "gru_mfma_kernel" if a.variant != "valu" else "gru_valu_kernel",
+                     "frac": tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
+                     "kernel": {"auto": "gru_mfma2_kernel", "mfma2": "gru_mfma2_kernel", "mfma": "gru_mfma_kernel",
+                                "valu": "gru_valu_kernel"}[a.variant],
                      "kernel_ms": 1e3 * kern_s, "flop_per_sample": FLOP_PER_SAMPLE,
                      "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": hbm_gbs / PEAK_HBM_GBS, "bytes_per_sample": BYTES_PER_SAMPLE}},

@@ -34,7 +34,7 @@ extern "C" {
 #define NTM_HIDDEN 64 /* the only hidden size compiled (every shipped checkpoint is HS[64]) */
 
 /* GRU kernel variants for ntm_gru_forward_ex:                              */
-#define NTM_GRU_AUTO 0  /* pick by B                                                        */
+#define NTM_GRU_AUTO 0  /* = NTM_GRU_MFMA2                                                  */
 #define NTM_GRU_MFMA 1  /* 16 streams / workgroup, 4 waves, v_mfma_f32_16x16x4_f32, h in LDS */
 #define NTM_GRU_VALU 2  /* 2 streams / wavefront, W_hh in VGPRs, h broadcast through LDS     */
 #define NTM_GRU_MFMA2 3 /* as MFMA, own-quarter-first step order: LDS exchange hidden by MFMAs */

@@ -26,6 +26,8 @@
 //     are loaded, so sigmoid and tanh start directly with v_exp_f32 (saves 12 VALU ops per step).
 #include "ntm_common.h"
 
+#include <type_traits>
+
 namespace ntm {
 
 namespace m2 {
@@ -78,14 +80,13 @@ __global__ __launch_bounds__(256) void debug_transpose_kernel(const float *in, f
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// STAMP = true is a DIAGNOSTIC build (ntm_debug_gru_stamps): s_memtime is issued (not waited for) at six
+// points of the step; the differences are accumulated once per step after a single wait.
 #define NTM2_STAMP(k)                                                                       \
     if constexpr (STAMP) {                                                                  \
-        unsigned long long now_;                                                            \
         __builtin_amdgcn_sched_barrier(0);                                                  \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");        \
+        asm volatile("s_memtime %0" : "=s"(ts_[k])::"memory");                              \
         __builtin_amdgcn_sched_barrier(0);                                                  \
-        seg[k] += now_ - last_;                                                             \
-        last_ = now_;                                                                       \
     }
 
 // ABL != 0 are DIAGNOSTIC instantiations (wrong results on purpose, never timed as product):
@@ -95,8 +96,8 @@ template <bool PRESCALE, bool STAMP, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 {
     using namespace m2;
-    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, last_ = 0;
-    (void)seg; (void)last_;
+    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, last_ = 0, ts_[6];
+    (void)seg; (void)last_; (void)ts_;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *hb = smem;                  // [2][4 k][16 stream][20]
     float *xb = hb + 2 * HB;           // [2][16][65]
@@ -203,10 +204,15 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         }
     }
     float *const yp_lane = yp + (w * 4 + q) * YP_Q + j * YS;
+    // LDS addresses of the h exchange (buffer 0; buffer 1 is a compile-time +HB in the unrolled loop)
+    const float *const hrd1 = hb + q * HB_K + j * HB_J + 4 * ((w + 1) & 3);
+    const float *const hrd2 = hb + q * HB_K + j * HB_J + 4 * ((w + 2) & 3);
+    const float *const hrd3 = hb + q * HB_K + j * HB_J + 4 * ((w + 3) & 3);
+    float *const hwr = hb + q * HB_K + j * HB_J + 4 * w;
 
     if constexpr (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
-    for (int64_t t = 0; t < T; ++t) {
-        const int cur = (int)(t & 1);
+    auto step = [&](const int64_t t, auto cur_c) {
+        constexpr int cur = decltype(cur_c)::value;   // == t & 1: which exchange buffer holds h_{t-1}
         const int ph = (int)(t & 63);
         const int64_t tile = t >> 6;
         float hB[16];
@@ -225,20 +231,25 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         // ops retire in order and the only younger one is the y partial write, which may stay in
         // flight -- its readers are two barriers away); three MFMAs are already in the pipe.
         if constexpr (ABL & 16) asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z)::"memory");
-        else asm volatile("s_waitcnt lgkmcnt(1)\n\ts_barrier" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z)::"memory");
+        else if constexpr (STAMP) {
+            NTM2_STAMP(0)   // step start .. own MFMAs 1-3 issued
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z)::"memory");
+            NTM2_STAMP(1)   // wait for the own h write
+            asm volatile("s_barrier" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z)::"memory");
+            NTM2_STAMP(2)   // barrier
+        } else asm volatile("s_waitcnt lgkmcnt(1)\n\ts_barrier" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z)::"memory");
         if constexpr (ABL & 2) {
 #pragma unroll
             for (int i = 4; i < 16; ++i) hB[i] = hT[i & 3];
         } else {
-            const float *rowp = hb + cur * HB + q * HB_K + j * HB_J;
+            const f32x4 v1 = *(const f32x4 *)(hrd1 + cur * HB);
+            const f32x4 v2 = *(const f32x4 *)(hrd2 + cur * HB);
+            const f32x4 v3 = *(const f32x4 *)(hrd3 + cur * HB);
 #pragma unroll
-            for (int c = 1; c < 4; ++c) {
-                const f32x4 v4 = *(const f32x4 *)(rowp + 4 * ((w + c) & 3));
-                hB[4 * c + 0] = v4.x; hB[4 * c + 1] = v4.y; hB[4 * c + 2] = v4.z; hB[4 * c + 3] = v4.w;
-            }
+            for (int i = 0; i < 4; ++i) { hB[4 + i] = v1[i]; hB[8 + i] = v2[i]; hB[12 + i] = v3[i]; }
         }
         // x of step t+1 (its tile was staged at ph 34 of the previous tile at the latest)
-        const float xn = xb[(((t + 1) >> 6) & 1) * SG * XS + j * XS + (int)((t + 1) & 63)];
+        float xn = xb[(((t + 1) >> 6) & 1) * SG * XS + j * XS + (int)((t + 1) & 63)];
 #pragma unroll
         for (int sg = 1; sg < ((ABL & 8) ? 4 : 16); ++sg) {
             acc_r = mfma16x(Ar[sg], hB[sg], acc_r);
@@ -246,8 +257,9 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
             acc_z = mfma16x(Az[sg], hB[sg], acc_z);
             if (sg == 3) asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z));
         }
-        asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z));
-        NTM2_STAMP(0)   // barrier + LDS reads + issue of the 48 MFMAs
+        // (xn is tied in so that its consumers -- the input terms of step t+1 -- stay out of the MFMA block)
+        asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z), "+v"(xn));
+        NTM2_STAMP(3)   // LDS reads + the other 45 MFMAs issued
 
         // tile housekeeping, once per 64 steps each (y partials of the previous tile are complete and
         // visible once step 64i+65 has passed its barrier)
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         // (pinned ahead of the gates: they fill the ~40 cycles the last MFMAs need to drain)
         asm volatile("" : "+v"(ncr[0]), "+v"(ncr[1]), "+v"(ncz[0]), "+v"(ncz[1]), "+v"(ngi[0]), "+v"(ngi[1]),
                           "+v"(acc_r), "+v"(acc_n), "+v"(acc_z));
-        NTM2_STAMP(1)   // housekeeping + input terms of step t+1
+
         const f32x2 one = {1.0f, 1.0f};
         f32x2 hn[2];
 #pragma unroll
@@ -295,16 +307,14 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
             hn[p] = __builtin_elementwise_fma(z, hold[p] - n, n);                         // n + z (h - n)
         }
         asm volatile("" : "+v"(hn[0]), "+v"(hn[1]));
-        NTM2_STAMP(2)   // gates (includes draining the last MFMAs)
+        NTM2_STAMP(4)   // housekeeping + input terms + gates
         // publish h_t first (it is on the critical path of every wave's next step) ...
 #pragma unroll
         for (int p = 0; p < 2; ++p) { hold[p] = hn[p]; cr[p] = ncr[p]; cz[p] = ncz[p]; gi[p] = ngi[p]; }
         hT[0] = hn[0][0]; hT[1] = hn[0][1]; hT[2] = hn[1][0]; hT[3] = hn[1][1];
-        NTM2_STAMP(3)
         if constexpr (!(ABL & 2))
-            *(f32x4 *)&hb[(cur ^ 1) * HB + q * HB_K + j * HB_J + 4 * w] = (f32x4){hT[0], hT[1], hT[2], hT[3]};
+            *(f32x4 *)(hwr + (cur ^ 1) * HB) = (f32x4){hT[0], hT[1], hT[2], hT[3]};
         asm volatile("" ::: "memory");   // keep the two LDS writes in this order (see the barrier's lgkmcnt)
-        NTM2_STAMP(4)   // ds_write_b128 (+ completion, stamped build only)
         // ... then the head partial of y_t over this lane's four units
         if constexpr (!(ABL & 4)) {
             const f32x2 pp = __builtin_elementwise_fma(hn[1], wo[1], hn[0] * wo[0]);
@@ -312,7 +322,18 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         } else {
             yp_lane[0] = 0.0f;           // keep the LDS-op count the barrier's lgkmcnt(1) relies on
         }
-        NTM2_STAMP(5)   // head partial + its ds_write
+        NTM2_STAMP(5)   // h write + head partial + y write issued
+        if constexpr (STAMP) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            seg[0] += ts_[0] - last_;
+#pragma unroll
+            for (int k = 1; k < 6; ++k) seg[k] += ts_[k] - ts_[k - 1];
+            last_ = ts_[5];
+        }
+    };
+    for (int64_t t = 0; t < T; t += 2) {
+        step(t, std::integral_constant<int, 0>{});
+        if (t + 1 < T) step(t + 1, std::integral_constant<int, 1>{});
     }
     if constexpr (STAMP) {
         if (a.dbg && l == 0)

@@ -45,7 +45,7 @@ int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, 
     if (!w_ih || !w_hh || !b_ih || !b_hh || !w_o || !x || !y) return fail(NTM_EINVAL, "ntm_gru_forward: null pointer");
     if (x_stride_b < T || y_stride_b < T) return fail(NTM_EINVAL, "ntm_gru_forward: stride < T");
     ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, x_stride_b, y_stride_b, nullptr, 0};
-    if (variant == NTM_GRU_AUTO) variant = NTM_GRU_MFMA;
+    if (variant == NTM_GRU_AUTO) variant = NTM_GRU_MFMA2;
     hipError_t e;
     switch (variant) {
         case NTM_GRU_MFMA: e = ntm::launch_gru_mfma(a, (hipStream_t)stream); break;

@@ -14,7 +14,7 @@ st = torch.zeros((B + 15) // 16, 4, 6, dtype=torch.int64, device="cuda")
 g, o = m.GRU, m.output
 L = ntm_amd._lib.lib()
 NAMES = {1: ["lds_read", "phaseA", "phaseB", "tail", "lds_write", "barrier"],
-         3: ["bar+48mfma", "hk+cinit", "gates", "head", "transpose", "ds_write"]}
+         3: ["mfma1-3(+bookkeeping)", "wait_own_wr", "barrier", "rd+45mfma", "hk+cinit+gates", "wr+head"]}
 for variant in (3, 1):
     for _ in range(2):
         rc = L.ntm_debug_gru_stamps(ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0),
