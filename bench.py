@@ -91,6 +91,53 @@ def cpu_baseline(w_name, seconds_budget=12.0):
     return res
 
 
+def side_workload(a):
+    """BASELINE configs[2] (DiffDelGRU-HS[64], CHOWTAPE_WOWFLUTTER weights) and configs[3] (TCN contrast
+    point) at the same batch; single GPU, not the headline metric."""
+    import ntm_amd
+    from ntm_amd import weights
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    B, T = a.batch, a.samples
+    x = synth_input(B, T, dev, seed=1234)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if a.workload == "diffdel":
+        model = ntm_amd.harness.build_model(weights.W_DIFFDEL, max_delay_seconds=0.0335, device=dev)   # D = 1847
+        g = torch.Generator(device=dev); g.manual_seed(77)
+        amp = 0.002 + 0.003 * torch.rand(B, 1, generator=g, device=dev)
+        wv = 0.5 + 1.5 * torch.rand(B, 1, generator=g, device=dev)
+        psi = 2 * np.pi * torch.rand(B, 1, generator=g, device=dev)
+        n = torch.arange(T, device=dev, dtype=torch.float32).unsqueeze(0)
+        d = torch.empty(B, T, device=dev)
+        for b0 in range(0, B, 256):
+            sl = slice(b0, min(B, b0 + 256))
+            d[sl] = FS * (0.0271 + amp[sl] * torch.sin(2 * np.pi * wv[sl] * n / FS + psi[sl])
+                          + 0.0005 * torch.sin(2 * np.pi * 23 * n / FS))
+        d = d.clamp_(0, model.max_delay).unsqueeze(1)
+        run = lambda: model.predict(x, d)[0]                                 # noqa: E731
+        name, bytes_per_sample = "DiffDelGRU-HS[64] CHOWTAPE_WOWFLUTTER weights, D=1847", 16
+    else:
+        model = ntm_amd.TCN().to(dev)
+        run = lambda: model(x)                                               # noqa: E731
+        name, bytes_per_sample = "TCN 4x(k13, dil 1/10/100/1000, 32 ch) seeded weights", 8
+    for _ in range(max(a.warmup, 1)):
+        y0 = run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ms = []
+    for _ in range(a.steps):
+        ev0.record(); y = run(); ev1.record(); torch.cuda.synchronize()
+        ms.append(ev0.elapsed_time(ev1))
+    elapsed = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": f"audio samples/sec (44.1 kHz) {a.workload}, batch={B}x{T}", "value": B * T * a.steps / elapsed,
+        "unit": "samples/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{name}, {B} segments x {T} samples fp32"},
+        "device_ms_per_step": float(np.mean(ms)), "bytes_per_sample": bytes_per_sample,
+        "checks": {"deterministic": bool(torch.equal(y, y0))}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,12 +147,16 @@ def main():
     ap.add_argument("--samples", type=int, default=65536, help="samples per segment")
     ap.add_argument("--variant", default="auto", choices=["auto", "mfma2", "mfma", "valu"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="gru", choices=["gru", "diffdel", "tcn"],
+                    help="gru = BASELINE configs[1] (the headline metric); diffdel = configs[2]; tcn = configs[3]")
     a = ap.parse_args()
 
     import ntm_amd
     from ntm_amd import distributed as D, weights
     from ntm_amd.model import esr_sums, ESR_EPS
 
+    if a.workload != "gru":
+        return side_workload(a)
     rank, world, local = D.init_from_env("nccl")
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs the MI355X"

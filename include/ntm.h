@@ -128,8 +128,9 @@ int ntm_esr_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t s
 
 /*
  * Builder-defined causal dilated-Conv1d TCN (BASELINE.json config 4; the reference has no TCN:
- * code/micro_tcn is an empty submodule).  Spec and parameter packing: DESIGN.md "K4" and
- * oracle/ntm_oracle.c:ntmo_tcn_forward.  x,y [B,T] contiguous; dil[L] host array; `scratch`
+ * code/micro_tcn is an empty submodule).  L causal blocks  out = PReLU(conv_dilated(in)) + conv1x1(in),
+ * then a 1x1 conv to one channel.  params (device), block after block:
+ *   W[C_in][K][C], b[C], alpha[C], R[C_in][C]   (C_in = 1 for block 0, C afterwards), then out_w[C], out_b[1].  x,y [B,T] contiguous; dil[L] host array; `scratch`
  * holds ntm_tcn_scratch_floats(B,T,C) floats.
  */
 int ntm_tcn_forward(const float *params, int L, int C, int K, const int *dil, const float *x,

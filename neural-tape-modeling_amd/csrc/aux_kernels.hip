@@ -142,8 +142,8 @@ hipError_t launch_esr(const float *y, const float *t, int64_t B, int64_t T, int6
 }
 
 // ---------------------------------------------------------------------------------------
-// K4: one TCN block  out[b][co][n] = PReLU(bias + sum_ci sum_k W[co][ci][k] in[b][ci][n-(K-1-k)dil])
-//                                    + sum_ci R[co][ci] in[b][ci][n]
+// K4: one TCN block  out[b][co][n] = PReLU(bias + sum_ci sum_k W[ci][k][co] in[b][ci][n-(K-1-k)dil])
+//                                    + sum_ci R[ci][co] in[b][ci][n]
 // One thread per sample, all CO outputs in registers; weights are wave-uniform (scalar loads).
 // First-correct version; see DESIGN.md for the planned MFMA formulation.
 // ---------------------------------------------------------------------------------------
@@ -164,11 +164,11 @@ __global__ __launch_bounds__(256) void tcn_block_kernel(const float *in, float *
             const int64_t src = n - (int64_t)(K - 1 - k) * dil;
             const float xv = src >= 0 ? ib[ci * T + src] : 0.0f;
 #pragma unroll
-            for (int co = 0; co < CO; ++co) acc[co] = __builtin_fmaf(W[(co * CI + ci) * K + k], xv, acc[co]);
+            for (int co = 0; co < CO; ++co) acc[co] = __builtin_fmaf(W[(ci * K + k) * CO + co], xv, acc[co]);
         }
         const float x0 = ib[ci * T + n];
 #pragma unroll
-        for (int co = 0; co < CO; ++co) res[co] = __builtin_fmaf(R[co * CI + ci], x0, res[co]);
+        for (int co = 0; co < CO; ++co) res[co] = __builtin_fmaf(R[ci * CO + co], x0, res[co]);
     }
     float *ob = out + b * CO * T;
 #pragma unroll

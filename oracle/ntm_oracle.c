@@ -179,7 +179,8 @@ int ntmo_esr_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t 
  *   v = PReLU(u, a_i[C_out])
  *   out = v + (res_w_i ? conv1x1(in, res_w_i[C_out,C_in]) : in)
  * followed by a 1x1 output conv (C->1, bias).  x [B,T] (C_in of block 0 is 1), y [B,T].
- * Parameters are packed block after block: W, b, a, res_w (always present), then out_w[C], out_b[1].
+ * Parameters are packed block after block: W[C_in][K][C_out], b[C_out], a[C_out], res_w[C_in][C_out]
+ * (always present), then out_w[C], out_b[1]  (output channel fastest: the layout the kernel streams).
  */
 int ntmo_tcn_forward(const float *params, int L, int C, int K, const int *dil, const float *x,
                      float *y, int64_t B, int64_t T)
@@ -202,11 +203,11 @@ int ntmo_tcn_forward(const float *params, int L, int C, int K, const int *dil, c
                     for (int ci = 0; ci < cin; ++ci)
                         for (int k = 0; k < K; ++k) {
                             const int64_t src = n - (int64_t)(K - 1 - k) * dil[l];
-                            if (src >= 0) u += W[((size_t)co * cin + ci) * K + k] * a[(size_t)ci * T + src];
+                            if (src >= 0) u += W[((size_t)ci * K + k) * C + co] * a[(size_t)ci * T + src];
                         }
                     const float v = u >= 0.0f ? u : alpha[co] * u;
                     float r = 0.0f;
-                    for (int ci = 0; ci < cin; ++ci) r += rw[(size_t)co * cin + ci] * a[(size_t)ci * T + n];
+                    for (int ci = 0; ci < cin; ++ci) r += rw[(size_t)ci * C + co] * a[(size_t)ci * T + n];
                     c[(size_t)co * T + n] = v + r;
                 }
             }

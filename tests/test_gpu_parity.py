@@ -302,3 +302,42 @@ def test_full_size_cfg2_checksum(ntm):
     y = m.predict(x)
     assert np.abs(y[0, 0].cpu().numpy() - g["y"][0, 0]).max() < TOL
     assert torch.equal(y, y[:1].expand_as(y))
+
+
+# ----------------------------------------------------------------------------- harness (test-model.py loss loop)
+def test_harness_compute_loss_gru_and_diffdel(ntm):
+    """code/test-model.py:332-398 on in-memory segments: predict, cut INIT_LEN, per-segment ESR, mean."""
+    g = load("g1_predict_16x8192.npz")
+    rng = np.random.default_rng(31)
+    x = g["x"]
+    target = (g["y"] + 0.01 * rng.standard_normal(g["y"].shape)).astype(np.float32)
+    m = ntm.harness.build_model(str(g["weights"]))
+    res, out = ntm.harness.compute_loss(m, dev(x).unsqueeze(1), dev(target).unsqueeze(1), INIT_LEN=1024)
+    yo, _ = oracle.gru_predict(oracle_weights(str(g["weights"])), x, threads=4)
+    want = float(np.mean(oracle.esr_per_segment(yo, target, 1024)))
+    assert res["segments"] == 16 and abs(res["ESR"] - want) < 1e-4 * want
+    assert np.abs(out.cpu().numpy()[:, 0] - g["y"]).max() < TOL
+    # DiffDelGRU through the same loop
+    g5 = load("g5_diffdel_predict.npz")
+    md = ntm.harness.build_model(str(g5["weights"]), max_delay_seconds=0.0335)
+    assert md.max_delay == int(g5["max_delay"])
+    tgt = dev(g5["y"])
+    res, out = ntm.harness.compute_loss(md, dev(g5["x"]), tgt, d_traj=dev(g5["d"]), INIT_LEN=ntm.harness.init_len(0.0335))
+    assert res["ESR"] < 1e-9 and res["segments"] == 1          # target == reference output
+    with pytest.raises(SystemExit):
+        ntm.harness.build_model("LSTM-HS[64]-L[ESR]-DS[x]")
+
+
+# ----------------------------------------------------------------------------- TCN (builder-defined)
+@pytest.mark.parametrize("B,T,dil", [(3, 700, (1, 3, 9, 27)), (2, 4000, (1, 10, 100, 1000)), (1, 1, (1, 10, 100, 1000))])
+def test_tcn_vs_oracle(ntm, B, T, dil):
+    m = ntm.TCN(dilations=dil).to("cuda")
+    rng = np.random.default_rng(B * 7 + T)
+    x = rng.uniform(-0.8, 0.8, (B, T)).astype(np.float32)
+    y = m(dev(x).unsqueeze(1)).cpu().numpy()[:, 0, :]
+    yo = oracle.tcn_forward(m.packed_params().cpu().numpy(), len(dil), 32, 13, dil, x)
+    assert np.abs(y - yo).max() < 2e-5
+    # causality: changing the future does not change the past
+    x2 = x.copy(); x2[:, T // 2:] += 1.0
+    y2 = m(dev(x2).unsqueeze(1)).cpu().numpy()[:, 0, :]
+    assert np.array_equal(y2[:, :T // 2], y[:, :T // 2])

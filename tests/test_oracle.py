@@ -133,3 +133,21 @@ def test_esr_definition():
     t64, y64 = t[:, 100:].astype(np.float64), y[:, 100:].astype(np.float64)
     want = np.mean((t64 - y64) ** 2, 1) / (np.mean(t64 ** 2, 1) + 1e-5)
     assert np.allclose(e, want, rtol=1e-6)
+
+
+def test_tcn_oracle_vs_torch_conv1d():
+    """The TCN has no reference implementation (parity unpinned): pin the C oracle to stock torch ops."""
+    import torch
+    import torch.nn.functional as F
+    import ntm_amd
+    m = ntm_amd.TCN(dilations=(1, 3, 9, 27))
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((2, 500)).astype(np.float32)
+    y = oracle.tcn_forward(m.packed_params().numpy(), 4, 32, 13, m.dilations, x)
+    a = torch.from_numpy(x).unsqueeze(1)
+    for W, b, al, R, d in zip(m.conv_weight, m.conv_bias, m.prelu, m.res_weight, m.dilations):
+        u = F.conv1d(F.pad(a, ((13 - 1) * d, 0)), W, b, dilation=d)
+        a = F.prelu(u, al) + F.conv1d(a, R)
+    want = F.conv1d(a, m.out_weight, m.out_bias)[:, 0, :].numpy()
+    assert np.abs(y - want).max() < 2e-5
+    assert m.receptive_field == 1 + 12 * 40
