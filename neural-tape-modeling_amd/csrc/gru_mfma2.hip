@@ -79,6 +79,20 @@ __global__ __launch_bounds__(256) void debug_transpose_kernel(const float *in, f
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+// fp32 x4 -> fp16 hi + fp16 lo (round to nearest both times): v = hi + lo to ~22 bits
+__device__ __forceinline__ void split_f16(const f32x4 v, f16x4 &hi, f16x4 &lo)
+{
+    hi = __builtin_convertvector(v, f16x4);
+    lo = __builtin_convertvector(v - __builtin_convertvector(hi, f32x4), f16x4);
+}
+__device__ __forceinline__ f32x4 pack_hl(const f16x4 hi, const f16x4 lo)
+{
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    const f16x8 v = __builtin_shufflevector(hi, lo, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(f32x4, v);
+}
 
 // STAMP = true is a DIAGNOSTIC build (ntm_debug_gru_stamps): s_memtime is issued (not waited for) at six
 // points of the step; the differences are accumulated once per step after a single wait.
@@ -92,7 +106,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // ABL != 0 are DIAGNOSTIC instantiations (wrong results on purpose, never timed as product):
 //   1 no gate math   2 no LDS exchange of h (barrier kept)   4 no head partial   8 no MFMAs on the
 //   other quarters   16 no barrier   32 no tile housekeeping
-template <bool PRESCALE, bool STAMP, int ABL = 0>
+// ENGINE 0: exact fp32 (v_mfma_f32_16x16x4_f32).
+// ENGINE 1: "f16x3" -- W and h are split into fp16 hi + lo parts (W = Wh + Wl, h = hh + hl, 22 significant
+//   bits each) and W.h is evaluated as Wh.hh + Wh.hl + Wl.hh on v_mfma_f32_16x16x16_f16 with fp32
+//   accumulation (products of fp16 pairs are exact in fp32; the dropped Wl.hl term is ~2^-22 relative).
+//   Everything outside the GEMV (state, gates, head) stays fp32.  Measured error vs the reference is
+//   the same as ENGINE 0's; 36 MFMAs x 17 cycles per step instead of 48 x 32.
+template <bool PRESCALE, bool STAMP, int ABL = 0, int ENGINE = 0>
 __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 {
     using namespace m2;
@@ -115,18 +135,34 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     constexpr float SN = PRESCALE ? 2.0f * LOG2E : 1.0f;   // scale of the n rows
 
     // ---- resident operands ---------------------------------------------------------------
-    // A[sigma] = W_g[16w + (l&15)][unit(s, l>>4)],  s = (sigma + 4w) & 15,  unit(s,k) = 16(s>>2) + 4k + (s&3)
+    // ENGINE 0: A[sigma] = W_g[16w + (l&15)][unit(s, l>>4)],  s = (sigma + 4w) & 15,
+    //           unit(s,k) = 16(s>>2) + 4k + (s&3)
+    // ENGINE 1: Ah/Al[g][c] = hi/lo fp16 parts of W_g[16w + (l&15)][16((w+c)&3) + 4(l>>4) + 0..3]
     float Ar[16], Az[16], An[16];
+    f16x4 Ah[3][4], Al[3][4];
     {
         const int row = 16 * w + j;
         const float *pr = a.w_hh + (size_t)(0 * kH + row) * kH + 4 * q;
         const float *pz = a.w_hh + (size_t)(1 * kH + row) * kH + 4 * q;
         const float *pn = a.w_hh + (size_t)(2 * kH + row) * kH + 4 * q;
+        if constexpr (ENGINE == 0) {
 #pragma unroll
-        for (int sg = 0; sg < 16; ++sg) {
-            const int s = (sg + 4 * w) & 15;
-            const int u0 = 16 * (s >> 2) + (s & 3);
-            Ar[sg] = pr[u0] * SRZ; Az[sg] = pz[u0] * SRZ; An[sg] = pn[u0] * SN;
+            for (int sg = 0; sg < 16; ++sg) {
+                const int s = (sg + 4 * w) & 15;
+                const int u0 = 16 * (s >> 2) + (s & 3);
+                Ar[sg] = pr[u0] * SRZ; Az[sg] = pz[u0] * SRZ; An[sg] = pn[u0] * SN;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int u0 = 16 * ((w + c) & 3);
+                const f32x4 vr = {pr[u0] * SRZ, pr[u0 + 1] * SRZ, pr[u0 + 2] * SRZ, pr[u0 + 3] * SRZ};
+                const f32x4 vn = {pn[u0] * SN, pn[u0 + 1] * SN, pn[u0 + 2] * SN, pn[u0 + 3] * SN};
+                const f32x4 vz = {pz[u0] * SRZ, pz[u0 + 1] * SRZ, pz[u0 + 2] * SRZ, pz[u0 + 3] * SRZ};
+                split_f16(vr, Ah[0][c], Al[0][c]);
+                split_f16(vn, Ah[1][c], Al[1][c]);
+                split_f16(vz, Ah[2][c], Al[2][c]);
+            }
         }
     }
     // per-lane gate parameters of units 16w+4q+v, as packed pairs (v = 0,1 | 2,3)
@@ -190,7 +226,10 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 
     // h_0: already in B-operand form for the own K-steps; publish it, prepare the input terms of step 0
     float hT[4] = {hold[0][0], hold[0][1], hold[1][0], hold[1][1]};
-    *(f32x4 *)&hb[0 * HB + q * HB_K + j * HB_J + 4 * w] = (f32x4){hT[0], hT[1], hT[2], hT[3]};
+    f16x4 hTh, hTl;                      // ENGINE 1: the same four values as fp16 hi / lo parts
+    split_f16((f32x4){hT[0], hT[1], hT[2], hT[3]}, hTh, hTl);
+    if constexpr (ENGINE == 0) *(f32x4 *)&hb[0 * HB + q * HB_K + j * HB_J + 4 * w] = (f32x4){hT[0], hT[1], hT[2], hT[3]};
+    else *(f32x4 *)&hb[0 * HB + q * HB_K + j * HB_J + 4 * w] = pack_hl(hTh, hTl);
     __syncthreads();   // x tile 0 visible (the h_0 writes are covered by step 0's barrier as well)
     f32x2 cr[2], cz[2], gi[2];
     {
@@ -216,17 +255,25 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         const int ph = (int)(t & 63);
         const int64_t tile = t >> 6;
         float hB[16];
+        f16x4 Bh[4], Bl[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) hB[i] = hT[i];
+        Bh[0] = hTh; Bl[0] = hTl;
 
-        // ---- the 48 MFMAs of the step, issued back to back: K-steps 0..3 (own quarter) come straight
-        //      from registers, the rest from the three ds_read_b128 issued behind the barrier ---------
+        // ---- the MFMAs of the step, issued back to back: the own quarter comes straight from
+        //      registers, the rest from the three ds_read_b128 issued behind the barrier ---------------
         f32x4 acc_r = {cr[0][0], cr[0][1], cr[1][0], cr[1][1]};
         f32x4 acc_n = {bhn[0][0], bhn[0][1], bhn[1][0], bhn[1][1]};
         f32x4 acc_z = {cz[0][0], cz[0][1], cz[1][0], cz[1][1]};
-        acc_r = mfma16x(Ar[0], hB[0], acc_r);
-        acc_n = mfma16x(An[0], hB[0], acc_n);
-        acc_z = mfma16x(Az[0], hB[0], acc_z);
+        if constexpr (ENGINE == 0) {
+            acc_r = mfma16x(Ar[0], hB[0], acc_r);
+            acc_n = mfma16x(An[0], hB[0], acc_n);
+            acc_z = mfma16x(Az[0], hB[0], acc_z);
+        } else {
+            acc_r = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[0][0], Bh[0], acc_r, 0, 0, 0);
+            acc_n = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[1][0], Bh[0], acc_n, 0, 0, 0);
+            acc_z = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[2][0], Bh[0], acc_z, 0, 0, 0);
+        }
         // the step's only barrier: every wave's ds_write_b128 of h_{t-1} has completed (lgkmcnt(1): LDS
         // ops retire in order and the only younger one is the y partial write, which may stay in
         // flight -- its readers are two barriers away); three MFMAs are already in the pipe.
@@ -245,17 +292,49 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
             const f32x4 v1 = *(const f32x4 *)(hrd1 + cur * HB);
             const f32x4 v2 = *(const f32x4 *)(hrd2 + cur * HB);
             const f32x4 v3 = *(const f32x4 *)(hrd3 + cur * HB);
+            if constexpr (ENGINE == 0) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { hB[4 + i] = v1[i]; hB[8 + i] = v2[i]; hB[12 + i] = v3[i]; }
+                for (int i = 0; i < 4; ++i) { hB[4 + i] = v1[i]; hB[8 + i] = v2[i]; hB[12 + i] = v3[i]; }
+            } else {
+                typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+                const f16x8 e1 = __builtin_bit_cast(f16x8, v1), e2 = __builtin_bit_cast(f16x8, v2),
+                            e3 = __builtin_bit_cast(f16x8, v3);
+                Bh[1] = __builtin_shufflevector(e1, e1, 0, 1, 2, 3); Bl[1] = __builtin_shufflevector(e1, e1, 4, 5, 6, 7);
+                Bh[2] = __builtin_shufflevector(e2, e2, 0, 1, 2, 3); Bl[2] = __builtin_shufflevector(e2, e2, 4, 5, 6, 7);
+                Bh[3] = __builtin_shufflevector(e3, e3, 0, 1, 2, 3); Bl[3] = __builtin_shufflevector(e3, e3, 4, 5, 6, 7);
+            }
         }
         // x of step t+1 (its tile was staged at ph 34 of the previous tile at the latest)
         float xn = xb[(((t + 1) >> 6) & 1) * SG * XS + j * XS + (int)((t + 1) & 63)];
+        if constexpr (ENGINE == 0) {
 #pragma unroll
-        for (int sg = 1; sg < ((ABL & 8) ? 4 : 16); ++sg) {
-            acc_r = mfma16x(Ar[sg], hB[sg], acc_r);
-            acc_n = mfma16x(An[sg], hB[sg], acc_n);
-            acc_z = mfma16x(Az[sg], hB[sg], acc_z);
-            if (sg == 3) asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z));
+            for (int sg = 1; sg < ((ABL & 8) ? 4 : 16); ++sg) {
+                acc_r = mfma16x(Ar[sg], hB[sg], acc_r);
+                acc_n = mfma16x(An[sg], hB[sg], acc_n);
+                acc_z = mfma16x(Az[sg], hB[sg], acc_z);
+                if (sg == 3) asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z));
+            }
+        } else {
+            // own quarter: the two cross terms; then the three other quarters, three terms each
+            acc_r = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[0][0], Bl[0], acc_r, 0, 0, 0);
+            acc_n = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[1][0], Bl[0], acc_n, 0, 0, 0);
+            acc_z = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[2][0], Bl[0], acc_z, 0, 0, 0);
+            acc_r = __builtin_amdgcn_mfma_f32_16x16x16f16(Al[0][0], Bh[0], acc_r, 0, 0, 0);
+            acc_n = __builtin_amdgcn_mfma_f32_16x16x16f16(Al[1][0], Bh[0], acc_n, 0, 0, 0);
+            acc_z = __builtin_amdgcn_mfma_f32_16x16x16f16(Al[2][0], Bh[0], acc_z, 0, 0, 0);
+            asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z));
+#pragma unroll
+            for (int c = 1; c < ((ABL & 8) ? 1 : 4); ++c) {
+                acc_r = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[0][c], Bh[c], acc_r, 0, 0, 0);
+                acc_n = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[1][c], Bh[c], acc_n, 0, 0, 0);
+                acc_z = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[2][c], Bh[c], acc_z, 0, 0, 0);
+                acc_r = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[0][c], Bl[c], acc_r, 0, 0, 0);
+                acc_n = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[1][c], Bl[c], acc_n, 0, 0, 0);
+                acc_z = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[2][c], Bl[c], acc_z, 0, 0, 0);
+                acc_r = __builtin_amdgcn_mfma_f32_16x16x16f16(Al[0][c], Bh[c], acc_r, 0, 0, 0);
+                acc_n = __builtin_amdgcn_mfma_f32_16x16x16f16(Al[1][c], Bh[c], acc_n, 0, 0, 0);
+                acc_z = __builtin_amdgcn_mfma_f32_16x16x16f16(Al[2][c], Bh[c], acc_z, 0, 0, 0);
+            }
         }
         // (xn is tied in so that its consumers -- the input terms of step t+1 -- stay out of the MFMA block)
         asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z), "+v"(xn));
@@ -312,8 +391,11 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 #pragma unroll
         for (int p = 0; p < 2; ++p) { hold[p] = hn[p]; cr[p] = ncr[p]; cz[p] = ncz[p]; gi[p] = ngi[p]; }
         hT[0] = hn[0][0]; hT[1] = hn[0][1]; hT[2] = hn[1][0]; hT[3] = hn[1][1];
-        if constexpr (!(ABL & 2))
-            *(f32x4 *)(hwr + (cur ^ 1) * HB) = (f32x4){hT[0], hT[1], hT[2], hT[3]};
+        if constexpr (ENGINE == 1) split_f16((f32x4){hT[0], hT[1], hT[2], hT[3]}, hTh, hTl);
+        if constexpr (!(ABL & 2)) {
+            if constexpr (ENGINE == 0) *(f32x4 *)(hwr + (cur ^ 1) * HB) = (f32x4){hT[0], hT[1], hT[2], hT[3]};
+            else *(f32x4 *)(hwr + (cur ^ 1) * HB) = pack_hl(hTh, hTl);
+        }
         asm volatile("" ::: "memory");   // keep the two LDS writes in this order (see the barrier's lgkmcnt)
         // ... then the head partial of y_t over this lane's four units
         if constexpr (!(ABL & 4)) {
@@ -374,6 +456,13 @@ hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream)
         NTM2_ABL_CASE(1) NTM2_ABL_CASE(2) NTM2_ABL_CASE(4) NTM2_ABL_CASE(8) NTM2_ABL_CASE(16) NTM2_ABL_CASE(32)
         NTM2_ABL_CASE(3) NTM2_ABL_CASE(7) NTM2_ABL_CASE(18) NTM2_ABL_CASE(39) NTM2_ABL_CASE(55) NTM2_ABL_CASE(63)
         default: break;
+    }
+    if (a.engine == 1) {
+        hipError_t e = hipFuncSetAttribute((const void *)gru_mfma2_kernel<true, false, 0, 1>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((gru_mfma2_kernel<true, false, 0, 1>), dim3(grid), dim3(256), smem_bytes, stream, a);
+        return hipGetLastError();
     }
     if (a.dbg) {
         hipError_t e = hipFuncSetAttribute((const void *)gru_mfma2_kernel<true, true>,

@@ -44,13 +44,14 @@ int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, 
     if (B == 0 || T == 0) return NTM_OK;
     if (!w_ih || !w_hh || !b_ih || !b_hh || !w_o || !x || !y) return fail(NTM_EINVAL, "ntm_gru_forward: null pointer");
     if (x_stride_b < T || y_stride_b < T) return fail(NTM_EINVAL, "ntm_gru_forward: stride < T");
-    ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, x_stride_b, y_stride_b, nullptr, 0};
+    ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, x_stride_b, y_stride_b, nullptr, 0, 0};
     if (variant == NTM_GRU_AUTO) variant = NTM_GRU_MFMA2;
     hipError_t e;
     switch (variant) {
         case NTM_GRU_MFMA: e = ntm::launch_gru_mfma(a, (hipStream_t)stream); break;
         case NTM_GRU_VALU: e = ntm::launch_gru_valu(a, (hipStream_t)stream); break;
         case NTM_GRU_MFMA2: e = ntm::launch_gru_mfma2(a, (hipStream_t)stream); break;
+        case NTM_GRU_F16X3: a.engine = 1; e = ntm::launch_gru_mfma2(a, (hipStream_t)stream); break;
         default: return fail(NTM_EINVAL, "ntm_gru_forward: unknown kernel variant");
     }
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_gru_forward");
@@ -69,7 +70,7 @@ int ntm_debug_gru_stamps(const float *w_ih, const float *w_hh, const float *b_ih
                          uint64_t *stamps, int variant, void *stream)
 {
     if (!stamps || !x || !y || B <= 0 || T <= 0) return fail(NTM_EINVAL, "ntm_debug_gru_stamps: bad argument");
-    ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, T, T, (unsigned long long *)stamps, 0};
+    ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, T, T, (unsigned long long *)stamps, 0, 0};
     hipError_t e = variant == NTM_GRU_MFMA ? ntm::launch_gru_mfma(a, (hipStream_t)stream)
                                            : ntm::launch_gru_mfma2(a, (hipStream_t)stream);
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_debug_gru_stamps");
@@ -80,7 +81,7 @@ int ntm_debug_gru_ablate(const float *w_ih, const float *w_hh, const float *b_ih
                          void *stream)
 {
     if (!x || !y || B <= 0 || T <= 0 || mask <= 0) return fail(NTM_EINVAL, "ntm_debug_gru_ablate: bad argument");
-    ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, T, T, nullptr, mask};
+    ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, T, T, nullptr, mask, 0};
     hipError_t e = ntm::launch_gru_mfma2(a, (hipStream_t)stream);
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_debug_gru_ablate");
 }

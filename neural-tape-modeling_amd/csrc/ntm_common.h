@@ -33,6 +33,7 @@ struct GruArgs {
     int64_t B, T, xs, ys;
     unsigned long long *dbg;  // diagnostic stamp sums (ntm_debug_gru_stamps), else null
     int abl;                  // diagnostic ablation mask (ntm_debug_gru_ablate), else 0
+    int engine;               // MFMA2 GEMV engine: 0 exact fp32, 1 split-fp16 x3 (NTM_GRU_F16X3)
 };
 
 }  // namespace ntm
