@@ -145,8 +145,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="segments per GPU")
     ap.add_argument("--samples", type=int, default=65536, help="samples per segment")
-    ap.add_argument("--variant", default="auto", choices=["auto", "mfma2", "mfma", "valu"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "mfma2", "mfma", "valu", "f16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the opt-in f16x3 kernel leg")
     ap.add_argument("--workload", default="gru", choices=["gru", "diffdel", "tcn"],
                     help="gru = BASELINE configs[1] (the headline metric); diffdel = configs[2]; tcn = configs[3]")
     a = ap.parse_args()
@@ -211,6 +212,34 @@ def main():
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
 
+    # ---- opt-in kernel variant, reported beside the headline (never part of `value`): the f16x3 GEMV
+    #      engine, checked over the whole batch against the exact-fp32 pass
+    extra = {}
+    if a.variant in ("auto", "mfma2") and not a.no_extra:
+        model.kernel_variant = "f16x3"
+        ms2 = []
+        for i in range(2 + 5):
+            y2, _ = one_pass(None)
+            torch.cuda.synchronize()
+            if i >= 2:
+                ms2.append(ev0.elapsed_time(ev1))
+        diff = (y2 - target).abs().max().item()
+        s2 = esr_sums(y2, target, skip=INIT_LEN).sum(dim=0)
+        k2 = float(np.mean(ms2)) / 1e3
+        extra["f16x3"] = {
+            "what": "same kernel with W.h evaluated as three fp16 hi/lo MFMA products, fp32 accumulate (opt-in)",
+            "kernel_ms": 1e3 * k2, "samples_per_s_kernel": B * T / k2,
+            "max_abs_diff_vs_exact_fp32_whole_batch": diff,
+            "esr_vs_exact_fp32_whole_batch": float(s2[0] / (s2[1] + ESR_EPS * B * (T - INIT_LEN)))}
+        # yardstick: two EXACT fp32 kernels that only differ in summation order (MFMA K order)
+        model.kernel_variant = "mfma"
+        y3, _ = one_pass(None)
+        extra["f16x3"]["yardstick_max_abs_diff_between_two_exact_fp32_kernels"] = (y3 - target).abs().max().item()
+        del y3
+        if gold is not None:
+            extra["f16x3"]["stream0_vs_reference_max_abs"] = float(
+                np.abs(gold["y"][0, 0] - y2[0, 0].cpu().numpy()).max())
+        model.kernel_variant = a.variant
     if rank != 0:
         return
     total_samples = float(B) * T * world * a.steps
@@ -245,12 +274,14 @@ def main():
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                      "frac": tflops / PEAK_FP32_TFLOPS, "traffic": traffic,
                      "kernel": {"auto": "gru_mfma2_kernel", "mfma2": "gru_mfma2_kernel", "mfma": "gru_mfma_kernel",
-                                "valu": "gru_valu_kernel"}[a.variant],
+                                "valu": "gru_valu_kernel", "f16x3": "gru_mfma2_kernel<f16x3>"}[a.variant],
                      "kernel_ms": 1e3 * kern_s, "flop_per_sample": FLOP_PER_SAMPLE,
                      "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": hbm_gbs / PEAK_HBM_GBS, "bytes_per_sample": BYTES_PER_SAMPLE}},
         "checks": checks,
     }
+    if extra:
+        out["other_kernels"] = extra
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(weights.W_GRU)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
