@@ -30,6 +30,10 @@
 
 namespace ntm {
 
+#ifndef NTM2_NB
+#define NTM2_NB 1
+#endif
+
 namespace m2 {
 constexpr int SG = 16;            // streams per workgroup
 constexpr int TT = 64;            // samples per x / y staging tile
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     const int64_t s0 = (int64_t)blockIdx.x * SG;
     const int64_t T = a.T;
     const bool valid = (s0 + j) < a.B;
+    constexpr int NB = NTM2_NB;   // own K-steps issued before the barrier (ENGINE 0)
     constexpr float LOG2E = 1.44269504088896340736f;
     constexpr float SRZ = PRESCALE ? -LOG2E : 1.0f;        // scale of the r and z rows
     constexpr float SN = PRESCALE ? 2.0f * LOG2E : 1.0f;   // scale of the n rows
@@ -266,9 +271,12 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         f32x4 acc_n = {bhn[0][0], bhn[0][1], bhn[1][0], bhn[1][1]};
         f32x4 acc_z = {cz[0][0], cz[0][1], cz[1][0], cz[1][1]};
         if constexpr (ENGINE == 0) {
-            acc_r = mfma16x(Ar[0], hB[0], acc_r);
-            acc_n = mfma16x(An[0], hB[0], acc_n);
-            acc_z = mfma16x(Az[0], hB[0], acc_z);
+#pragma unroll
+            for (int sg = 0; sg < NB; ++sg) {
+                acc_r = mfma16x(Ar[sg], hB[sg], acc_r);
+                acc_n = mfma16x(An[sg], hB[sg], acc_n);
+                acc_z = mfma16x(Az[sg], hB[sg], acc_z);
+            }
         } else {
             acc_r = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[0][0], Bh[0], acc_r, 0, 0, 0);
             acc_n = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[1][0], Bh[0], acc_n, 0, 0, 0);
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         float xn = xb[(((t + 1) >> 6) & 1) * SG * XS + j * XS + (int)((t + 1) & 63)];
         if constexpr (ENGINE == 0) {
 #pragma unroll
-            for (int sg = 1; sg < ((ABL & 8) ? 4 : 16); ++sg) {
+            for (int sg = NB; sg < ((ABL & 8) ? 4 : 16); ++sg) {
                 acc_r = mfma16x(Ar[sg], hB[sg], acc_r);
                 acc_n = mfma16x(An[sg], hB[sg], acc_n);
                 acc_z = mfma16x(Az[sg], hB[sg], acc_z);
