@@ -84,6 +84,8 @@ __global__ __launch_bounds__(256) void debug_transpose_kernel(const float *in, f
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 // fp32 x4 -> fp16 hi + fp16 lo (round to nearest both times): v = hi + lo to ~22 bits
 __device__ __forceinline__ void split_f16(const f32x4 v, f16x4 &hi, f16x4 &lo)
@@ -115,7 +117,9 @@ __device__ __forceinline__ f32x4 pack_hl(const f16x4 hi, const f16x4 lo)
 //   bits each) and W.h is evaluated as Wh.hh + Wh.hl + Wl.hh on v_mfma_f32_16x16x16_f16 with fp32
 //   accumulation (products of fp16 pairs are exact in fp32; the dropped Wl.hl term is ~2^-22 relative).
 //   Everything outside the GEMV (state, gates, head) stays fp32.  Measured error vs the reference is
-//   the same as ENGINE 0's; 36 MFMAs x 17 cycles per step instead of 48 x 32.
+//   the same as ENGINE 0's.  Per step and wave 27 MFMAs of ~17 cycles instead of 48 x 32:
+//   own quarter 9 x K16, the two other quarters that are adjacent in the exchange row as 9 x K32
+//   (v_mfma_f32_16x16x32_f16), the remaining quarter 9 x K16.
 template <bool PRESCALE, bool STAMP, int ABL = 0, int ENGINE = 0>
 __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 {
@@ -142,9 +146,13 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     // ---- resident operands ---------------------------------------------------------------
     // ENGINE 0: A[sigma] = W_g[16w + (l&15)][unit(s, l>>4)],  s = (sigma + 4w) & 15,
     //           unit(s,k) = 16(s>>2) + 4k + (s&3)
-    // ENGINE 1: Ah/Al[g][c] = hi/lo fp16 parts of W_g[16w + (l&15)][16((w+c)&3) + 4(l>>4) + 0..3]
+    // ENGINE 1: hi/lo fp16 parts of W_g[16w + (l&15)][16 Q + 4(l>>4) + 0..3] for quarter Q:
+    //           Ah/Al[g][0] Q = w (own), Ah/Al[g][1] Q = w^1 (single), A8h/A8l[g] Q = pa, pa+1 (pair,
+    //           pa = 2 for waves 0,1 and 0 for waves 2,3: the half of the row that does not hold w)
     float Ar[16], Az[16], An[16];
-    f16x4 Ah[3][4], Al[3][4];
+    f16x4 Ah[3][2], Al[3][2];
+    f16x8 A8h[3], A8l[3];
+    const int pa = (w < 2) ? 2 : 0;
     {
         const int row = 16 * w + j;
         const float *pr = a.w_hh + (size_t)(0 * kH + row) * kH + 4 * q;
@@ -158,15 +166,21 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
                 Ar[sg] = pr[u0] * SRZ; Az[sg] = pz[u0] * SRZ; An[sg] = pn[u0] * SN;
             }
         } else {
+            const float *pg[3] = {pr, pn, pz};
+            const float sc[3] = {SRZ, SN, SRZ};
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int u0 = 16 * ((w + c) & 3);
-                const f32x4 vr = {pr[u0] * SRZ, pr[u0 + 1] * SRZ, pr[u0 + 2] * SRZ, pr[u0 + 3] * SRZ};
-                const f32x4 vn = {pn[u0] * SN, pn[u0 + 1] * SN, pn[u0 + 2] * SN, pn[u0 + 3] * SN};
-                const f32x4 vz = {pz[u0] * SRZ, pz[u0 + 1] * SRZ, pz[u0 + 2] * SRZ, pz[u0 + 3] * SRZ};
-                split_f16(vr, Ah[0][c], Al[0][c]);
-                split_f16(vn, Ah[1][c], Al[1][c]);
-                split_f16(vz, Ah[2][c], Al[2][c]);
+            for (int g = 0; g < 3; ++g) {
+                auto quarter = [&](int Q, f16x4 &hi, f16x4 &lo) {
+                    const float *p = pg[g] + 16 * Q;
+                    split_f16((f32x4){p[0] * sc[g], p[1] * sc[g], p[2] * sc[g], p[3] * sc[g]}, hi, lo);
+                };
+                f16x4 h0, l0, h1, l1;
+                quarter(w, Ah[g][0], Al[g][0]);
+                quarter(w ^ 1, Ah[g][1], Al[g][1]);
+                quarter(pa, h0, l0);
+                quarter(pa + 1, h1, l1);
+                A8h[g] = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+                A8l[g] = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
             }
         }
     }
@@ -234,7 +248,11 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     f16x4 hTh, hTl;                      // ENGINE 1: the same four values as fp16 hi / lo parts
     split_f16((f32x4){hT[0], hT[1], hT[2], hT[3]}, hTh, hTl);
     if constexpr (ENGINE == 0) *(f32x4 *)&hb[0 * HB + q * HB_K + j * HB_J + 4 * w] = (f32x4){hT[0], hT[1], hT[2], hT[3]};
-    else *(f32x4 *)&hb[0 * HB + q * HB_K + j * HB_J + 4 * w] = pack_hl(hTh, hTl);
+    else {
+        // ENGINE 1 exchange row (kg, j): [hi q0 | hi q1 | hi q2 | hi q3 | lo q0 | lo q1 | lo q2 | lo q3], 8 B each
+        *(f16x4 *)&hb[0 * HB + q * HB_K + j * HB_J + 2 * w] = hTh;
+        *(f16x4 *)&hb[0 * HB + q * HB_K + j * HB_J + 8 + 2 * w] = hTl;
+    }
     __syncthreads();   // x tile 0 visible (the h_0 writes are covered by step 0's barrier as well)
     f32x2 cr[2], cz[2], gi[2];
     {
@@ -253,6 +271,8 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     const float *const hrd2 = hb + q * HB_K + j * HB_J + 4 * ((w + 2) & 3);
     const float *const hrd3 = hb + q * HB_K + j * HB_J + 4 * ((w + 3) & 3);
     float *const hwr = hb + q * HB_K + j * HB_J + 4 * w;
+    float *const hrow = hb + q * HB_K + j * HB_J;   // ENGINE 1 addressing
+    const int ps = w ^ 1;
 
     if constexpr (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
     auto step = [&](const int64_t t, auto cur_c) {
@@ -260,7 +280,8 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         const int ph = (int)(t & 63);
         const int64_t tile = t >> 6;
         float hB[16];
-        f16x4 Bh[4], Bl[4];
+        f16x4 Bh[2], Bl[2];
+        f16x8 B8h, B8l;
 #pragma unroll
         for (int i = 0; i < 4; ++i) hB[i] = hT[i];
         Bh[0] = hTh; Bl[0] = hTl;
@@ -296,21 +317,20 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         if constexpr (ABL & 2) {
 #pragma unroll
             for (int i = 4; i < 16; ++i) hB[i] = hT[i & 3];
-        } else {
+        } else if constexpr (ENGINE == 0) {
             const f32x4 v1 = *(const f32x4 *)(hrd1 + cur * HB);
             const f32x4 v2 = *(const f32x4 *)(hrd2 + cur * HB);
             const f32x4 v3 = *(const f32x4 *)(hrd3 + cur * HB);
             if constexpr (ENGINE == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { hB[4 + i] = v1[i]; hB[8 + i] = v2[i]; hB[12 + i] = v3[i]; }
-            } else {
-                typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-                const f16x8 e1 = __builtin_bit_cast(f16x8, v1), e2 = __builtin_bit_cast(f16x8, v2),
-                            e3 = __builtin_bit_cast(f16x8, v3);
-                Bh[1] = __builtin_shufflevector(e1, e1, 0, 1, 2, 3); Bl[1] = __builtin_shufflevector(e1, e1, 4, 5, 6, 7);
-                Bh[2] = __builtin_shufflevector(e2, e2, 0, 1, 2, 3); Bl[2] = __builtin_shufflevector(e2, e2, 4, 5, 6, 7);
-                Bh[3] = __builtin_shufflevector(e3, e3, 0, 1, 2, 3); Bl[3] = __builtin_shufflevector(e3, e3, 4, 5, 6, 7);
             }
+        }
+        if constexpr (ENGINE == 1 && !(ABL & 2)) {
+            B8h = *(const f16x8 *)(hrow + cur * HB + 2 * pa);
+            B8l = *(const f16x8 *)(hrow + cur * HB + 8 + 2 * pa);
+            Bh[1] = *(const f16x4 *)(hrow + cur * HB + 2 * ps);
+            Bl[1] = *(const f16x4 *)(hrow + cur * HB + 8 + 2 * ps);
         }
         // x of step t+1 (its tile was staged at ph 34 of the previous tile at the latest)
         float xn = xb[(((t + 1) >> 6) & 1) * SG * XS + j * XS + (int)((t + 1) & 63)];
@@ -323,7 +343,8 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
                 if (sg == 3) asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z));
             }
         } else {
-            // own quarter: the two cross terms; then the three other quarters, three terms each
+            // own quarter: the two cross terms; then the adjacent pair of other quarters as K=32 MFMAs and
+            // the remaining quarter as K=16, three terms each
             acc_r = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[0][0], Bl[0], acc_r, 0, 0, 0);
             acc_n = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[1][0], Bl[0], acc_n, 0, 0, 0);
             acc_z = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[2][0], Bl[0], acc_z, 0, 0, 0);
@@ -331,17 +352,25 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
             acc_n = __builtin_amdgcn_mfma_f32_16x16x16f16(Al[1][0], Bh[0], acc_n, 0, 0, 0);
             acc_z = __builtin_amdgcn_mfma_f32_16x16x16f16(Al[2][0], Bh[0], acc_z, 0, 0, 0);
             asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z));
-#pragma unroll
-            for (int c = 1; c < ((ABL & 8) ? 1 : 4); ++c) {
-                acc_r = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[0][c], Bh[c], acc_r, 0, 0, 0);
-                acc_n = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[1][c], Bh[c], acc_n, 0, 0, 0);
-                acc_z = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[2][c], Bh[c], acc_z, 0, 0, 0);
-                acc_r = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[0][c], Bl[c], acc_r, 0, 0, 0);
-                acc_n = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[1][c], Bl[c], acc_n, 0, 0, 0);
-                acc_z = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[2][c], Bl[c], acc_z, 0, 0, 0);
-                acc_r = __builtin_amdgcn_mfma_f32_16x16x16f16(Al[0][c], Bh[c], acc_r, 0, 0, 0);
-                acc_n = __builtin_amdgcn_mfma_f32_16x16x16f16(Al[1][c], Bh[c], acc_n, 0, 0, 0);
-                acc_z = __builtin_amdgcn_mfma_f32_16x16x16f16(Al[2][c], Bh[c], acc_z, 0, 0, 0);
+            if constexpr (!(ABL & 8)) {
+                acc_r = __builtin_amdgcn_mfma_f32_16x16x32_f16(A8h[0], B8h, acc_r, 0, 0, 0);
+                acc_n = __builtin_amdgcn_mfma_f32_16x16x32_f16(A8h[1], B8h, acc_n, 0, 0, 0);
+                acc_z = __builtin_amdgcn_mfma_f32_16x16x32_f16(A8h[2], B8h, acc_z, 0, 0, 0);
+                acc_r = __builtin_amdgcn_mfma_f32_16x16x32_f16(A8h[0], B8l, acc_r, 0, 0, 0);
+                acc_n = __builtin_amdgcn_mfma_f32_16x16x32_f16(A8h[1], B8l, acc_n, 0, 0, 0);
+                acc_z = __builtin_amdgcn_mfma_f32_16x16x32_f16(A8h[2], B8l, acc_z, 0, 0, 0);
+                acc_r = __builtin_amdgcn_mfma_f32_16x16x32_f16(A8l[0], B8h, acc_r, 0, 0, 0);
+                acc_n = __builtin_amdgcn_mfma_f32_16x16x32_f16(A8l[1], B8h, acc_n, 0, 0, 0);
+                acc_z = __builtin_amdgcn_mfma_f32_16x16x32_f16(A8l[2], B8h, acc_z, 0, 0, 0);
+                acc_r = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[0][1], Bh[1], acc_r, 0, 0, 0);
+                acc_n = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[1][1], Bh[1], acc_n, 0, 0, 0);
+                acc_z = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[2][1], Bh[1], acc_z, 0, 0, 0);
+                acc_r = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[0][1], Bl[1], acc_r, 0, 0, 0);
+                acc_n = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[1][1], Bl[1], acc_n, 0, 0, 0);
+                acc_z = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[2][1], Bl[1], acc_z, 0, 0, 0);
+                acc_r = __builtin_amdgcn_mfma_f32_16x16x16f16(Al[0][1], Bh[1], acc_r, 0, 0, 0);
+                acc_n = __builtin_amdgcn_mfma_f32_16x16x16f16(Al[1][1], Bh[1], acc_n, 0, 0, 0);
+                acc_z = __builtin_amdgcn_mfma_f32_16x16x16f16(Al[2][1], Bh[1], acc_z, 0, 0, 0);
             }
         }
         // (xn is tied in so that its consumers -- the input terms of step t+1 -- stay out of the MFMA block)
@@ -402,7 +431,10 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         if constexpr (ENGINE == 1) split_f16((f32x4){hT[0], hT[1], hT[2], hT[3]}, hTh, hTl);
         if constexpr (!(ABL & 2)) {
             if constexpr (ENGINE == 0) *(f32x4 *)(hwr + (cur ^ 1) * HB) = (f32x4){hT[0], hT[1], hT[2], hT[3]};
-            else *(f32x4 *)(hwr + (cur ^ 1) * HB) = pack_hl(hTh, hTl);
+            else {
+                *(f16x4 *)(hrow + (cur ^ 1) * HB + 2 * w) = hTh;
+                *(f16x4 *)(hrow + (cur ^ 1) * HB + 8 + 2 * w) = hTl;
+            }
         }
         asm volatile("" ::: "memory");   // keep the two LDS writes in this order (see the barrier's lgkmcnt)
         // ... then the head partial of y_t over this lane's four units

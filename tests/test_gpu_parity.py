@@ -341,3 +341,22 @@ def test_tcn_vs_oracle(ntm, B, T, dil):
     x2 = x.copy(); x2[:, T // 2:] += 1.0
     y2 = m(dev(x2).unsqueeze(1)).cpu().numpy()[:, 0, :]
     assert np.array_equal(y2[:, :T // 2], y[:, :T // 2])
+
+
+def test_f16x3_engine_against_exact_fp32_on_hot_input(ntm):
+    """The opt-in f16x3 GEMV engine on a loud, noisy input (|x| up to 0.95, 8192 steps): within the
+    path's 1e-5 bar of the oracle, and as close to the exact-fp32 kernel as two exact-fp32 kernels
+    with different summation order are to each other."""
+    B, T = 512, 8192
+    rng = np.random.default_rng(77)
+    x = rng.uniform(-0.95, 0.95, (B, T)).astype(np.float32)
+    xd = dev(x).unsqueeze(1)
+    ys = {}
+    for variant in ("mfma2", "f16x3", "mfma"):
+        ys[variant] = make_rnn(ntm, W_G, variant).predict(xd)[:, 0]
+    yo, _ = oracle.gru_predict(oracle_weights(W_G), x[:8], threads=4)
+    assert np.abs(ys["f16x3"][:8].cpu().numpy() - yo).max() < TOL
+    d_f16 = (ys["f16x3"] - ys["mfma2"]).abs().max().item()
+    d_f32 = (ys["mfma"] - ys["mfma2"]).abs().max().item()
+    assert d_f16 < TOL
+    assert d_f16 < 3 * max(d_f32, 1e-6), (d_f16, d_f32)
