@@ -1,5 +1,5 @@
-// K2 (time-varying fractional delay line), K3 (ESR partial sums), K4 (causal dilated Conv1d TCN).
-// All three are streaming kernels: coalesced 4-16 B/lane global accesses, no MFMA.
+// K2 (time-varying fractional delay line) and K3 (ESR partial sums): streaming kernels, coalesced
+// 4-16 B/lane global accesses, no MFMA.  (K4, the TCN, lives in tcn_kernels.hip.)
 #include "ntm_common.h"
 
 namespace ntm {
@@ -138,81 +138,6 @@ hipError_t launch_esr(const float *y, const float *t, int64_t B, int64_t T, int6
     if (splits > want) splits = want;
     if (splits < 1) splits = 1;
     hipLaunchKernelGGL(esr_sums_kernel, dim3((unsigned)B, (unsigned)splits), dim3(256), 0, stream, y, t, T, skip, out);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------
-// K4: one TCN block  out[b][co][n] = PReLU(bias + sum_ci sum_k W[ci][k][co] in[b][ci][n-(K-1-k)dil])
-//                                    + sum_ci R[ci][co] in[b][ci][n]
-// One thread per sample, all CO outputs in registers; weights are wave-uniform (scalar loads).
-// First-correct version; see DESIGN.md for the planned MFMA formulation.
-// ---------------------------------------------------------------------------------------
-template <int CO>
-__global__ __launch_bounds__(256) void tcn_block_kernel(const float *in, float *out, const float *W, const float *bias,
-                                                        const float *alpha, const float *R, int CI, int K, int dil,
-                                                        int64_t T)
-{
-    const int64_t b = blockIdx.x;
-    const int64_t n = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
-    if (n >= T) return;
-    const float *ib = in + b * CI * T;
-    float acc[CO], res[CO];
-#pragma unroll
-    for (int co = 0; co < CO; ++co) { acc[co] = bias[co]; res[co] = 0.0f; }
-    for (int ci = 0; ci < CI; ++ci) {
-        for (int k = 0; k < K; ++k) {
-            const int64_t src = n - (int64_t)(K - 1 - k) * dil;
-            const float xv = src >= 0 ? ib[ci * T + src] : 0.0f;
-#pragma unroll
-            for (int co = 0; co < CO; ++co) acc[co] = __builtin_fmaf(W[(ci * K + k) * CO + co], xv, acc[co]);
-        }
-        const float x0 = ib[ci * T + n];
-#pragma unroll
-        for (int co = 0; co < CO; ++co) res[co] = __builtin_fmaf(R[ci * CO + co], x0, res[co]);
-    }
-    float *ob = out + b * CO * T;
-#pragma unroll
-    for (int co = 0; co < CO; ++co) {
-        const float u = acc[co];
-        ob[co * T + n] = (u >= 0.0f ? u : alpha[co] * u) + res[co];
-    }
-}
-
-template <int C>
-__global__ __launch_bounds__(256) void tcn_out_kernel(const float *in, float *y, const float *ow, const float *ob,
-                                                      int64_t T)
-{
-    const int64_t b = blockIdx.x;
-    const int64_t n = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
-    if (n >= T) return;
-    float acc = ob[0];
-#pragma unroll
-    for (int ci = 0; ci < C; ++ci) acc = __builtin_fmaf(ow[ci], in[(b * C + ci) * T + n], acc);
-    y[b * T + n] = acc;
-}
-
-hipError_t launch_tcn(const float *params, int L, int C, int K, const int *dil, const float *x, float *y, int64_t B,
-                      int64_t T, float *scratch, hipStream_t stream)
-{
-    if (B == 0 || T == 0) return hipSuccess;
-    if (C != 32) return hipErrorInvalidValue;
-    float *bufA = scratch, *bufB = scratch + (size_t)B * C * T;
-    const float *in = x;
-    int cin = 1;
-    const float *p = params;
-    const dim3 grid((unsigned)B, (unsigned)((T + 255) / 256));
-    for (int l = 0; l < L; ++l) {
-        const float *W = p;      p += (size_t)C * cin * K;
-        const float *bias = p;   p += C;
-        const float *alpha = p;  p += C;
-        const float *R = p;      p += (size_t)C * cin;
-        float *out = (l & 1) ? bufB : bufA;
-        hipLaunchKernelGGL(tcn_block_kernel<32>, grid, dim3(256), 0, stream, in, out, W, bias, alpha, R, cin, K, dil[l],
-                           T);
-        in = out;
-        cin = C;
-    }
-    hipLaunchKernelGGL(tcn_out_kernel<32>, grid, dim3(256), 0, stream, in, y, p, p + C, T);
     return hipGetLastError();
 }
 

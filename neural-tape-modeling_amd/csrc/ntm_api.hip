@@ -141,7 +141,7 @@ int ntm_tcn_forward(const float *params, int L, int C, int K, const int *dil, co
                     int64_t T, float *scratch, void *stream)
 {
     if (L <= 0 || K <= 0 || B < 0 || T < 0) return fail(NTM_EINVAL, "ntm_tcn_forward: bad size");
-    if (C != 32) return fail(NTM_EINVAL, "ntm_tcn_forward: only C = 32 channels is compiled");
+    if (C != 32 || K != 13) return fail(NTM_EINVAL, "ntm_tcn_forward: only C = 32 channels, K = 13 taps is compiled");
     if (B == 0 || T == 0) return NTM_OK;
     if (!params || !dil || !x || !y || !scratch) return fail(NTM_EINVAL, "ntm_tcn_forward: null pointer");
     hipError_t e = ntm::launch_tcn(params, L, C, K, dil, x, y, B, T, scratch, (hipStream_t)stream);
