@@ -48,3 +48,21 @@ def compute_loss(model, input, target, d_traj=None, INIT_LEN=1024):
     res = distributed.reduce_loss_sums(per_seg, s)
     res["ESR"] = res.pop("mean_segment_loss")
     return res, output
+
+
+@torch.no_grad()
+def apply_delay(delay, delay_trajectory, output, segment_length=None):
+    """code/test-model.py:259-290 (`--ADD_DELAY` with `--MODEL GRU`), in working order: the reference
+    calls `delay.init_buffer(N)` without the `max_d` argument its own class requires
+    (code/model.py:326) and therefore raises TypeError; here the buffer is re-initialised to zeros with
+    the delay line's current max_delay, then the trajectory is applied -- in one launch, or in the
+    reference's 4096-sample chunks when `segment_length=2**12` (same numbers, state is carried)."""
+    delay.init_buffer(output.shape[0], delay.max_delay)
+    if segment_length is None:
+        return delay(output, delay_trajectory)
+    T = output.shape[-1]
+    out = torch.empty(output.shape, device=output.device, dtype=torch.float32)
+    for i in range(-(-T // segment_length)):
+        sl = slice(i * segment_length, (i + 1) * segment_length)
+        out[:, :, sl] = delay(output[:, :, sl], delay_trajectory[:, :, sl])
+    return out

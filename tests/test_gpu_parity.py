@@ -360,3 +360,16 @@ def test_f16x3_engine_against_exact_fp32_on_hot_input(ntm):
     d_f32 = (ys["mfma"] - ys["mfma2"]).abs().max().item()
     assert d_f16 < TOL
     assert d_f16 < 3 * max(d_f32, 1e-6), (d_f16, d_f32)
+
+
+def test_apply_delay_working_version(ntm):
+    """`--ADD_DELAY` path of code/test-model.py:259-290 (broken in the reference: missing max_d)."""
+    rng = np.random.default_rng(5)
+    B, T, D = 3, 10000, 1846
+    y = rng.standard_normal((B, T)).astype(np.float32)
+    d = (900 + 800 * np.sin(np.arange(T) / 700.0))[None, :].repeat(B, 0).astype(np.float32)
+    dl = ntm.TimeVaryingDelayLine(max_delay=D)
+    a = ntm.harness.apply_delay(dl, dev(d).unsqueeze(1), dev(y).unsqueeze(1))
+    b = ntm.harness.apply_delay(dl, dev(d).unsqueeze(1), dev(y).unsqueeze(1), segment_length=2**12)
+    yo, _ = oracle.delay_forward(y, d, np.zeros((B, D), np.float32))
+    assert np.array_equal(a.cpu().numpy()[:, 0], yo) and torch.equal(a, b)
