@@ -1,16 +1,14 @@
 // K4: builder-defined causal dilated-Conv1d TCN (BASELINE configs[3]; the reference has no TCN).
 //   block:  out[n][co] = PReLU(b[co] + sum_{ci,k} W[ci][k][co] in[n-(K-1-k)dil][ci]) + sum_ci R[ci][co] in[n][ci]
-// Activations between blocks are channels-last [B][T][32] so that a lane fetches 8 consecutive input
-// channels with two 16-B loads.  Blocks with 32 input channels run on the matrix pipe (exact fp32
-// v_mfma_f32_16x16x4_f32): M = 16 output channels (A = weights, resident in VGPRs: 112 per lane),
-// N = 16 samples (B = input), K = 32x13 taps + 32 residual; the 1-channel first block and the 1x1 output
-// conv are plain VALU kernels (< 4 % of the flops).
+// Activations between blocks are channels-last [B][T][32].  Blocks with 32 input channels run on the matrix
+// pipe (exact fp32 v_mfma_f32_16x16x4_f32): M = 16 output channels (A = weights, resident in VGPRs: 112 per
+// lane), N = 16 samples (B = input rows from LDS), K = 32x13 taps + 32 residual; the 1-channel first block and
+// the 1x1 output conv are plain VALU kernels (< 4 % of the flops).
 //
-// Measured (512 x 65 536, MI355X): 12.7 ms per 32->32 block = 75 TFLOP/s, the matrix pipe 50 % busy, 39 % of
-// the wave cycles in s_waitcnt.  Every input row is fetched 13 x (taps) x 2 (the two waves that share a
-// sample range) = 26 times into L1; at 112 GB per block that L1-fill traffic, not HBM or the MFMA rate, is
-// the bound, for every dilation alike.  Next step: polyphase tile order (16 outputs
-// n = p + m d per tile) so that consecutive taps reuse the same rows from L1/LDS.
+// History (MI355X, 512 x 65 536): a first MFMA version that fetched B operands straight from global memory
+// in natural sample order ran 12.7 ms per block with the matrix pipe 50 % busy: every input row was fetched
+// 13 x (taps) x 2 (waves sharing a sample range) = 26 times through L1, for every dilation alike.  The
+// polyphase tile order + LDS staging below fetches each row once per tile: 8.3 ms per block.
 #include "ntm_common.h"
 
 #include <type_traits>
@@ -21,7 +19,6 @@ __device__ float tcn_zeros[32];   // zero page for taps that fall before the sta
 
 constexpr int TC = 32;    // channels
 constexpr int TK = 13;    // kernel size
-constexpr int TCH = 8192; // samples per workgroup (weights are loaded once per workgroup)
 
 // ---- first block: 1 input channel, x [B][T] -> out [B][T][32] -------------------------------------
 // thread -> (sample, group of 4 output channels): a wave writes 8 samples x 128 B = 1 KiB contiguous.
@@ -49,24 +46,36 @@ __global__ __launch_bounds__(256) void tcn_first_kernel(const float *x, float *o
     *(f32x4 *)(out + (b * T + n) * TC + 4 * c4) = v;
 }
 
-// ---- 32 -> 32 channel block on the matrix pipe -----------------------------------------------------
-// workgroup = (stream b, chunk of TCH samples), 4 waves: wave w computes output channels 16(w&1)..+15 for
-// the samples 64(w>>1)..+63 of every 128-sample iteration (4 N-tiles of 16 samples).
-// A[i][kslot] (lane i = l&15, kslot = l>>4):  conv K-step (k,s): W[ci = 8 kslot + s][k][co = 16 mt + i]
-// B[kslot][j] (lane j = l&15, kslot = l>>4):  in[n0 + j - (12-k) dil][ci = 8 kslot + s]   (8 ci per lane = 2 x 16 B)
-// D: lane (q = l>>4, j): sample n0 + j, channels 16 mt + 4 q + v  -> one 16-B store.
-__global__ __launch_bounds__(256, 1) void tcn_block_mfma_kernel(const float *in, float *out, const float *W,
-                                                                const float *bias, const float *alpha, const float *R,
-                                                                int dil, int64_t T)
+// ---- 32 -> 32 channel block, polyphase tile order + LDS staging (the one launch_tcn uses) -------------
+// A tile is 16 outputs of ONE phase of the dilation: n = p + (m0 + j) dil, j = 0..15.  Its 13 taps read the
+// rows m0 + j + k - 12 of the same phase, so consecutive taps reuse the same 28 input rows: they are staged
+// once in LDS (register-staged one iteration ahead) and the B operands of all 13 x 8 K-steps are
+// ds_read_b128 from there -- every input row is fetched from global memory once per tile (1.75x instead of
+// 26x), for every dilation alike.  Tiles of a stream are numbered tau = p * tpp + m0/16 (tpp = tiles per
+// phase); a workgroup takes TPW consecutive tiles, 8 per iteration: wave pair ng = w>>1 owns 4 of them,
+// wave mt = w&1 of the pair computes output channels 16 mt .. +15.
+constexpr int TROWS = 28;                  // 16 outputs + 12 taps of history
+constexpr int TRS = 36;                    // floats per LDS row: 32 channels + 4 pad (b128 reads conflict-light)
+constexpr int TILE_F = TROWS * TRS;        // 1008 floats per tile window
+constexpr int TPW = 512;                   // tiles per workgroup
+constexpr int TCN2_SMEM_FLOATS = 2 * 2 * 4 * TILE_F;   // [buffer][pair][tile]  = 64 512 B
+
+__global__ __launch_bounds__(256, 1) void tcn_block_mfma2_kernel(const float *in, float *out, const float *W,
+                                                                 const float *bias, const float *alpha,
+                                                                 const float *R, int dil, int64_t T, int tpp,
+                                                                 int total_tiles)
 {
+    extern __shared__ __attribute__((aligned(16))) float tsm[];
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mt = w & 1, ng = w >> 1;
     const int q = l >> 4, j = l & 15;
     const int64_t b = blockIdx.x;
-    const int64_t c0 = (int64_t)blockIdx.y * TCH;
     const float *ib = in + b * T * TC;
     float *ob = out + b * T * TC;
+    const int tile0 = blockIdx.y * TPW;
+    const int tiles_end = (tile0 + TPW < total_tiles) ? tile0 + TPW : total_tiles;
+    const int niter = (tiles_end - tile0 + 7) / 8;
 
     float Aw[TK][8], Ar[8];
 #pragma unroll
@@ -79,61 +88,89 @@ __global__ __launch_bounds__(256, 1) void tcn_block_mfma_kernel(const float *in,
 #pragma unroll
     for (int v = 0; v < 4; ++v) { bi[v] = bias[16 * mt + 4 * q + v]; al[v] = alpha[16 * mt + 4 * q + v]; }
 
-    const int64_t cend = (c0 + TCH < T) ? c0 + TCH : T;
-    const int lane_off = j * TC + 8 * q;             // floats, loop-invariant
-    const int64_t halo = (int64_t)(TK - 1) * dil;
-    // one 128-sample iteration; CHECK = false on interior iterations (every tap inside [0,T)): the tap
-    // address is a wave-uniform base plus the invariant lane offset, no per-lane arithmetic at all
-    auto iteration = [&](const int64_t it0, auto check_c) {
-        constexpr bool CHECK = decltype(check_c)::value;
-        const int64_t nb = it0 + 64 * ng;            // first sample of this wave's four N-tiles
+    // staging: the pair's 4 windows = 112 rows x 8 pieces of 16 B = 896 pieces over its 128 lanes (7 each)
+    int st_nt[7], st_roff[7], st_lds[7];
+    int64_t st_goff[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+        const int e = mt * 64 + l + 128 * c;
+        const int nt = e / 224, r = (e % 224) >> 3, c8 = e & 7;
+        st_nt[c] = nt;
+        st_roff[c] = r - (TK - 1);                                  // row relative to the tile's first output
+        st_goff[c] = (int64_t)(r - (TK - 1)) * dil * TC + 4 * c8;    // floats, relative to the tile's first output
+        st_lds[c] = (ng * 4 + nt) * TILE_F + r * TRS + 4 * c8;
+    }
+    // first output sample of tile tau (>= T for tiles beyond the end) and whether the tile starts a phase
+    auto tile_n0 = [&](int tau, bool &first) -> int64_t {
+        if (tau >= tiles_end) { first = false; return T; }
+        const int p = tau / tpp, t = tau - p * tpp;
+        first = (t == 0);
+        return (int64_t)p + (int64_t)(16 * t) * dil;
+    };
+    f32x4 sreg[7];
+    auto stage_load = [&](int it) {
+        int64_t n0[4]; bool fst[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) n0[nt] = tile_n0(tile0 + 8 * it + 4 * ng + nt, fst[nt]);
+#pragma unroll
+        for (int c = 0; c < 7; ++c) {
+            const int nt = st_nt[c];
+            const int64_t base = nt == 0 ? n0[0] : nt == 1 ? n0[1] : nt == 2 ? n0[2] : n0[3];
+            const bool f = nt == 0 ? fst[0] : nt == 1 ? fst[1] : nt == 2 ? fst[2] : fst[3];
+            const int64_t n = base + (int64_t)st_roff[c] * dil;
+            const bool ok = n < T && !(f && st_roff[c] < 0);
+            const float *ptr = ok ? ib + base * TC + st_goff[c] : tcn_zeros + (st_goff[c] & 31);
+            sreg[c] = *(const f32x4 *)ptr;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int c = 0; c < 7; ++c) *(f32x4 *)&tsm[buf * (TCN2_SMEM_FLOATS / 2) + st_lds[c]] = sreg[c];
+    };
+    const int rd_base = (ng * 4) * TILE_F + j * TRS + 8 * q;   // + nt*TILE_F + k*TRS (+4 for the upper 4 channels)
+
+    if (niter <= 0) return;
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int it = 0; it < niter; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < niter) stage_load(it + 1);
+        const float *tb = tsm + buf * (TCN2_SMEM_FLOATS / 2) + rd_base;
         f32x4 acc[4], res[4];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) { acc[nt] = bi; res[nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
-        auto load_tap = [&](int k, f32x4 (&lo)[4], f32x4 (&hi)[4]) {
-            const int64_t shift = (int64_t)(TK - 1 - k) * dil;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const float *base = ib + (nb + 16 * nt - shift) * TC;     // wave-uniform
-                const f32x4 *p = (const f32x4 *)(base + lane_off);
-                if constexpr (CHECK) {
-                    const int64_t src = nb + 16 * nt + j - shift;
-                    if (!(src >= 0 && src < T)) p = (const f32x4 *)(tcn_zeros + 8 * q);
-                }
-                lo[nt] = p[0]; hi[nt] = p[1];
-            }
-        };
-        f32x4 blo[2][4], bhi[2][4];
-        load_tap(0, blo[0], bhi[0]);
 #pragma unroll
         for (int k = 0; k < TK; ++k) {
-            const int cb = k & 1;
-            // the loads of tap k+1 are requested before the 32 MFMAs of tap k
-            if (k + 1 < TK) load_tap(k + 1, blo[cb ^ 1], bhi[cb ^ 1]);
+            f32x4 lo[4], hi[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                lo[nt] = *(const f32x4 *)(tb + nt * TILE_F + k * TRS);
+                hi[nt] = *(const f32x4 *)(tb + nt * TILE_F + k * TRS + 4);
+            }
 #pragma unroll
             for (int s = 0; s < 8; ++s)
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    const float bv = s < 4 ? blo[cb][nt][s] : bhi[cb][nt][s - 4];
+                    const float bv = s < 4 ? lo[nt][s] : hi[nt][s - 4];
                     acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[k][s], bv, acc[nt], 0, 0, 0);
                     if (k == TK - 1) res[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[s], bv, res[nt], 0, 0, 0);
                 }
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const int64_t n = nb + 16 * nt + j;
+            bool fst;
+            const int64_t n = tile_n0(tile0 + 8 * it + 4 * ng + nt, fst) + (int64_t)j * dil;
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float u = acc[nt][e];
                 v[e] = (u >= 0.0f ? u : al[e] * u) + res[nt][e];
             }
-            if (!CHECK || n < T) *(f32x4 *)(ob + n * TC + 16 * mt + 4 * q) = v;
+            if (n < T) *(f32x4 *)(ob + n * TC + 16 * mt + 4 * q) = v;
         }
-    };
-    for (int64_t it0 = c0; it0 < cend; it0 += 128) {
-        if (it0 >= halo && it0 + 128 <= T) iteration(it0, std::false_type{});
-        else iteration(it0, std::true_type{});
+        if (it + 1 < niter) stage_store(buf ^ 1);
+        __syncthreads();
     }
 }
 
@@ -164,7 +201,6 @@ hipError_t launch_tcn(const float *params, int L, int C, int K, const int *dil, 
     const float *p = params;
     const dim3 grid1((unsigned)B, (unsigned)((T + 255) / 256));
     const dim3 gridf((unsigned)B, (unsigned)((T + 31) / 32));
-    const dim3 gridm((unsigned)B, (unsigned)((T + TCH - 1) / TCH));
     const float *in = x;
     int cin = 1;
     for (int l = 0; l < L; ++l) {
@@ -174,7 +210,16 @@ hipError_t launch_tcn(const float *params, int L, int C, int K, const int *dil, 
         const float *R = p;      p += (size_t)C * cin;
         float *out = (l & 1) ? bufB : bufA;
         if (cin == 1) hipLaunchKernelGGL(tcn_first_kernel, gridf, dim3(256), 0, stream, in, out, W, bias, alpha, R, dil[l], T);
-        else hipLaunchKernelGGL(tcn_block_mfma_kernel, gridm, dim3(256), 0, stream, in, out, W, bias, alpha, R, dil[l], T);
+        else {
+            // polyphase tiles: M = ceil(T / dil) outputs per phase, tpp = ceil(M / 16) tiles per phase
+            const int64_t M = (T + dil[l] - 1) / dil[l];
+            const int tpp = (int)((M + 15) / 16);
+            const int64_t total = (int64_t)dil[l] * tpp;
+            if (dil[l] <= 0 || total > (int64_t)1 << 30) return hipErrorInvalidValue;
+            const dim3 gridp((unsigned)B, (unsigned)((total + TPW - 1) / TPW));
+            hipLaunchKernelGGL(tcn_block_mfma2_kernel, gridp, dim3(256), TCN2_SMEM_FLOATS * sizeof(float), stream, in,
+                               out, W, bias, alpha, R, dil[l], T, tpp, (int)total);
+        }
         in = out;
         cin = C;
     }
