@@ -398,12 +398,10 @@ hipError_t launch_gru_mfma(const GruArgs &a, hipStream_t stream)
     // (each workgroup wants all four SIMDs to itself).
     static const size_t smem_bytes = 96 * 1024;
     static_assert(MFMA_SMEM_FLOATS * sizeof(float) <= 96 * 1024, "LDS carve-up");
-    static bool attr_set = false;
-    if (!attr_set) {
+    {
         hipError_t e = hipFuncSetAttribute((const void *)gru_mfma_kernel<false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const unsigned grid = (unsigned)((a.B + SG - 1) / SG);
     if (a.dbg) {

@@ -476,12 +476,10 @@ hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream)
 {
     static const size_t smem_bytes = m2::SMEM_FLOATS * sizeof(float);   // 151 680 B: one workgroup per CU
     static_assert(m2::SMEM_FLOATS * sizeof(float) <= 160 * 1024, "LDS carve-up");
-    static bool attr_set = false;
-    if (!attr_set) {
+    {   // per launch: the attribute is per device, and one process may drive several
         hipError_t e = hipFuncSetAttribute((const void *)gru_mfma2_kernel<true, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     const unsigned grid = (unsigned)((a.B + m2::SG - 1) / m2::SG);
 #define NTM2_ABL_CASE(M)                                                                                   \

@@ -399,6 +399,4 @@ def test_diagnostic_entry_points_run(ntm):
     y = torch.empty_like(x); h = torch.zeros(B, 64, device="cuda")
     assert L.ntm_debug_gru_ablate(P(g.weight_ih_l0), P(g.weight_hh_l0), P(g.bias_ih_l0), P(g.bias_hh_l0), P(o.weight),
                                   P(o.bias), P(x), P(y), B, T, P(h), 4, None) == 0
-    assert L.ntm_debug_gru_ablate(P(g.weight_ih_l0), P(g.weight_hh_l0), P(g.bias_ih_l0), P(g.bias_hh_l0), P(o.weight),
-                                  P(o.bias), P(x), P(y), B, T, P(h), 5, None) == -2 or True   # uncompiled mask: falls through
     torch.cuda.synchronize()
