@@ -26,6 +26,7 @@
 //     are loaded, so sigmoid and tanh start directly with v_exp_f32 (saves 12 VALU ops per step).
 #include "ntm_common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace ntm {
@@ -43,8 +44,7 @@ constexpr int HB = 4 * HB_K;      // 1280 floats per buffer
 constexpr int XS = TT + 1;        // x tile row (conflict-free column reads)
 constexpr int YS = TT + 4;        // y partial row: 16-B aligned rows for ds_read_b128 at flush
 constexpr int YP_Q = SG * YS;     // 1088 floats per partial plane
-constexpr int YP_N = 16;          // partial planes per tile buffer: (wave, lane group)
-constexpr int SMEM_FLOATS = 2 * HB + 2 * SG * XS + 2 * YP_N * YP_Q;
+constexpr int smem_floats(int ypn) { return 2 * HB + 2 * SG * XS + 2 * ypn * YP_Q; }   // ypn partial planes per y tile
 static_assert((2 * HB + 2 * SG * XS) % 4 == 0 && YS % 4 == 0 && YP_Q % 4 == 0, "y partial rows must be 16-B aligned");
 }  // namespace m2
 
@@ -120,7 +120,12 @@ __device__ __forceinline__ f32x4 pack_hl(const f16x4 hi, const f16x4 lo)
 //   the same as ENGINE 0's.  Per step and wave 27 MFMAs of ~17 cycles instead of 48 x 32:
 //   own quarter 9 x K16, the two other quarters that are adjacent in the exchange row as 9 x K32
 //   (v_mfma_f32_16x16x32_f16), the remaining quarter 9 x K16.
-template <bool PRESCALE, bool STAMP, int ABL = 0, int ENGINE = 0>
+// YPN = 16: every lane parks its 4-unit head partial (16 planes per y tile, 152 KB of LDS, one workgroup per
+//   CU -- right for B <= 4096 where a CU has a single 16-stream group anyway).
+// YPN = 4: the four lane groups of a wave are summed first (two permlane swaps), 4 planes, 53 KB of LDS:
+//   two or three workgroups share a CU and one group's MFMAs overlap another group's gate math
+//   (overlap only exists across waves) -- used when B >= 8192.
+template <bool PRESCALE, bool STAMP, int ABL = 0, int ENGINE = 0, int YPN = 16>
 __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 {
     using namespace m2;
@@ -221,10 +226,10 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     // group) are summed in a fixed order (deterministic), one ds_read_b128 per plane.
     const bool y_vec_ok = ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) && ((a.ys & 3) == 0);
     auto flush_y_tile = [&](int64_t tile) {
-        const float *src = yp + (tile & 1) * YP_N * YP_Q + (tid >> 4) * YS + 4 * (tid & 15);
+        const float *src = yp + (tile & 1) * YPN * YP_Q + (tid >> 4) * YS + 4 * (tid & 15);
         f32x4 v = {bo, bo, bo, bo};
 #pragma unroll
-        for (int pl = 0; pl < YP_N; ++pl) v += *(const f32x4 *)(src + pl * YP_Q);
+        for (int pl = 0; pl < YPN; ++pl) v += *(const f32x4 *)(src + pl * YP_Q);
         const int64_t gs = s0 + (tid >> 4), gt = tile * TT + 4 * (tid & 15);
         if (gs < a.B) {
             float *dst = a.y + gs * a.ys + gt;
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
             gi[p] = __builtin_elementwise_fma(win[p], xx, bin_[p]);
         }
     }
-    float *const yp_lane = yp + (w * 4 + q) * YP_Q + j * YS;
+    float *const yp_lane = yp + (YPN == 16 ? w * 4 + q : w) * YP_Q + j * YS;
     // LDS addresses of the h exchange (buffer 0; buffer 1 is a compile-time +HB in the unrolled loop)
     const float *const hrd1 = hb + q * HB_K + j * HB_J + 4 * ((w + 1) & 3);
     const float *const hrd2 = hb + q * HB_K + j * HB_J + 4 * ((w + 2) & 3);
@@ -440,7 +445,19 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         // ... then the head partial of y_t over this lane's four units
         if constexpr (!(ABL & 4)) {
             const f32x2 pp = __builtin_elementwise_fma(hn[1], wo[1], hn[0] * wo[0]);
-            yp_lane[(tile & 1) * YP_N * YP_Q + ph] = pp[0] + pp[1];
+            float hp = pp[0] + pp[1];
+            if constexpr (YPN == 4) {   // sum the wave's four lane groups; all four then store the same value
+                // v_permlane*_swap exchanges halves of TWO registers in place; with a copy of hp as the second
+                // one, the two results sum to hp(l) + hp(l^32) resp. hp(l) + hp(l^16).  Written as asm: hipcc
+                // (ROCm 7.2) folds the builtin's two results into one register when both operands hold the
+                // same value.  Wait states around the swap are inside the string (cdna_hip_programming.md 5.7).
+                float hq;
+                asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(hp), "=&v"(hq));
+                hp += hq;
+                asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(hp), "=&v"(hq));
+                hp += hq;
+            }
+            yp_lane[(tile & 1) * YPN * YP_Q + ph] = hp;
         } else {
             yp_lane[0] = 0.0f;           // keep the LDS-op count the barrier's lgkmcnt(1) relies on
         }
@@ -472,45 +489,36 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     }
 }
 
+template <typename K>
+static hipError_t launch_m2(K kernel, size_t smem_bytes, unsigned grid, const GruArgs &a, hipStream_t stream)
+{
+    // per launch: the attribute is per device, and one process may drive several
+    hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), smem_bytes, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream)
 {
-    static const size_t smem_bytes = m2::SMEM_FLOATS * sizeof(float);   // 151 680 B: one workgroup per CU
-    static_assert(m2::SMEM_FLOATS * sizeof(float) <= 160 * 1024, "LDS carve-up");
-    {   // per launch: the attribute is per device, and one process may drive several
-        hipError_t e = hipFuncSetAttribute((const void *)gru_mfma2_kernel<true, false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
-        if (e != hipSuccess) return e;
-    }
+    constexpr size_t smem16 = m2::smem_floats(16) * sizeof(float);   // 151 680 B: one workgroup per CU
+    constexpr size_t smem4 = m2::smem_floats(4) * sizeof(float);     //  53 376 B: up to three per CU
+    static_assert(smem16 <= 160 * 1024, "LDS carve-up");
     const unsigned grid = (unsigned)((a.B + m2::SG - 1) / m2::SG);
-#define NTM2_ABL_CASE(M)                                                                                   \
-    case M: {                                                                                              \
-        hipError_t e = hipFuncSetAttribute((const void *)gru_mfma2_kernel<true, false, M>,                 \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);   \
-        if (e != hipSuccess) return e;                                                                     \
-        hipLaunchKernelGGL((gru_mfma2_kernel<true, false, M>), dim3(grid), dim3(256), smem_bytes, stream, a); \
-        return hipGetLastError();                                                                          \
-    }
+    const char *force = getenv("NTM_FORCE_PLANES");                 // test hook: "4" or "16"
+    const bool many = force ? (force[0] == '4') : grid >= 512;       // >= 2 stream groups per CU
+#define NTM2_ABL_CASE(M) case M: return launch_m2(gru_mfma2_kernel<true, false, M>, smem16, grid, a, stream);
     switch (a.abl) {
         NTM2_ABL_CASE(1) NTM2_ABL_CASE(2) NTM2_ABL_CASE(4) NTM2_ABL_CASE(8) NTM2_ABL_CASE(16) NTM2_ABL_CASE(32)
         NTM2_ABL_CASE(3) NTM2_ABL_CASE(7) NTM2_ABL_CASE(18) NTM2_ABL_CASE(39) NTM2_ABL_CASE(55) NTM2_ABL_CASE(63)
         default: break;
     }
-    if (a.engine == 1) {
-        hipError_t e = hipFuncSetAttribute((const void *)gru_mfma2_kernel<true, false, 0, 1>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((gru_mfma2_kernel<true, false, 0, 1>), dim3(grid), dim3(256), smem_bytes, stream, a);
-        return hipGetLastError();
-    }
-    if (a.dbg) {
-        hipError_t e = hipFuncSetAttribute((const void *)gru_mfma2_kernel<true, true>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL((gru_mfma2_kernel<true, true>), dim3(grid), dim3(256), smem_bytes, stream, a);
-    } else {
-        hipLaunchKernelGGL((gru_mfma2_kernel<true, false>), dim3(grid), dim3(256), smem_bytes, stream, a);
-    }
-    return hipGetLastError();
+    if (a.dbg) return launch_m2(gru_mfma2_kernel<true, true>, smem16, grid, a, stream);
+    if (a.engine == 1)
+        return many ? launch_m2(gru_mfma2_kernel<true, false, 0, 1, 4>, smem4, grid, a, stream)
+                    : launch_m2(gru_mfma2_kernel<true, false, 0, 1, 16>, smem16, grid, a, stream);
+    return many ? launch_m2(gru_mfma2_kernel<true, false, 0, 0, 4>, smem4, grid, a, stream)
+                : launch_m2(gru_mfma2_kernel<true, false, 0, 0, 16>, smem16, grid, a, stream);
 }
 
 hipError_t launch_debug_transpose(const float *in, float *out, hipStream_t stream)

@@ -137,6 +137,24 @@ def test_ragged_shapes_vs_oracle(ntm, variant, B, T):
     assert np.abs(m.hidden.cpu().numpy()[0] - ho).max() < TOL
 
 
+@pytest.mark.parametrize("variant", ["mfma2", "f16x3"])
+def test_many_groups_variant(ntm, variant):
+    """B >= 8192 selects the small-LDS build of the MFMA2 kernel (several workgroups per CU, head partial
+    pre-reduced with permlane swaps): check it against the oracle and against the one-per-CU build."""
+    B, T = 8192 + 16, 192
+    rng = np.random.default_rng(4)
+    base = rng.uniform(-0.6, 0.6, (8, T)).astype(np.float32)
+    x = np.tile(base, (B // 8, 1))
+    m = make_rnn(ntm, W_G, variant)
+    y = m.predict(dev(x).unsqueeze(1))[:, 0]
+    yo, _ = oracle.gru_predict(oracle_weights(W_G), base)
+    assert np.abs(y[:8].cpu().numpy() - yo).max() < TOL
+    yv = y.view(B // 8, 8, T)
+    assert torch.equal(yv, yv[:1].expand_as(yv))
+    y_small = m.predict(dev(x[:64]).unsqueeze(1))[:, 0]          # B = 64: the 16-plane build
+    assert (y_small - y[:64]).abs().max().item() < 2e-6          # (plane summation order differs)
+
+
 def test_variants_agree_and_raw_abi_strides(ntm):
     """Call the C ABI directly: row strides > T, NULL h_state, both kernels."""
     L = ntm._lib.lib()
