@@ -128,6 +128,15 @@ int ntm_esr_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t s
                  void *stream);
 
 /*
+ * As ntm_esr_sums, on the DC-blocked signals: both y and t pass H(z) = (1 - z^-1)/(1 - R z^-1) (zero state
+ * at sample `skip`) before the sums are taken -- the `DCPreESR(dc_pre=True)` loss of code/test-model.py:252
+ * and code/train.py:173-174 (GreyBoxDRC, un-vendored: parity unpinned; upstream truncates the impulse
+ * response to 2000 taps, this is the untruncated recursion).  R = 0.995 upstream.
+ */
+int ntm_esr_dcpre_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, float R,
+                       double *out, void *stream);
+
+/*
  * Builder-defined causal dilated-Conv1d TCN (BASELINE.json config 4; the reference has no TCN:
  * code/micro_tcn is an empty submodule).  L causal blocks  out = PReLU(conv_dilated(in)) + conv1x1(in),
  * then a 1x1 conv to one channel.  params (device), block after block:

@@ -31,6 +31,7 @@ _SIGNATURES = {
     "ntm_diffdel_gru_forward": (_int, [_vp] * 5 + [_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _int,
                                                    _vp, _vp, _vp]),
     "ntm_esr_sums": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+    "ntm_esr_dcpre_sums": (_int, [_vp, _vp, _i64, _i64, _i64, ctypes.c_float, _vp, _vp]),
     "ntm_tcn_forward": (_int, [_vp, _int, _int, _int, ctypes.POINTER(_int), _vp, _vp, _i64, _i64, _vp, _vp]),
     "ntm_tcn_scratch_floats": (_i64, [_i64, _i64, _int]),
 }

@@ -141,4 +141,94 @@ hipError_t launch_esr(const float *y, const float *t, int64_t B, int64_t T, int6
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------
+// K3b: DC-pre-emphasised ESR sums: both signals through H(z) = (1 - z^-1)/(1 - R z^-1) (zero state at
+// `skip`), then sum f(t-y)^2 and sum f(t)^2 per stream.  The recursion v[n] = R v[n-1] + u[n] is linear, so a
+// 256-thread block scans 4096 samples at a time: every thread runs its 16 samples from zero state, the
+// (R^16, end value) pairs are combined by a shuffle scan, and the incoming carry is added as R^(k+1) c.
+// ---------------------------------------------------------------------------------------
+constexpr int DCL = 16;   // samples per thread per chunk
+
+__global__ __launch_bounds__(256) void esr_dcpre_kernel(const float *y, const float *t, int64_t T, int64_t skip, float R,
+                                                        double *out)
+{
+    const int64_t b = blockIdx.x;
+    const float *yb = y + b * T, *tb = t + b * T;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float rp[DCL + 1];                       // R^0 .. R^16
+    rp[0] = 1.0f;
+#pragma unroll
+    for (int k = 1; k <= DCL; ++k) rp[k] = rp[k - 1] * R;
+    __shared__ float wA[4], wBe[4], wBt[4], carry[2];
+    if (tid == 0) { carry[0] = 0.0f; carry[1] = 0.0f; }
+    double se = 0.0, st = 0.0;
+    for (int64_t c0 = skip; c0 < T; c0 += 256 * DCL) {
+        __syncthreads();
+        const float cin_e = carry[0], cin_t = carry[1];
+        const int64_t n0 = c0 + (int64_t)tid * DCL;
+        float ue[DCL], ut[DCL];
+        float pe = 0.0f, pt = 0.0f;
+        if (n0 > skip && n0 - 1 < T) { pt = tb[n0 - 1]; pe = pt - yb[n0 - 1]; }
+        float fe = 0.0f, ft = 0.0f;
+#pragma unroll
+        for (int k = 0; k < DCL; ++k) {
+            const int64_t n = n0 + k;
+            float tv = 0.0f, ev = 0.0f;
+            if (n < T) { tv = tb[n]; ev = tv - yb[n]; } else { tv = pt; ev = pe; }   // past the end: u = 0
+            fe = (ev - pe) + R * fe;
+            ft = (tv - pt) + R * ft;
+            pe = ev; pt = tv;
+            ue[k] = fe; ut[k] = ft;          // response from zero state
+        }
+        // inclusive scan of (A, Be, Bt) over the wave: (A2,B2) o (A1,B1) = (A1 A2, A2 B1 + B2)
+        float A = rp[DCL], Be = fe, Bt = ft;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float Ap = __shfl_up(A, off), Bep = __shfl_up(Be, off), Btp = __shfl_up(Bt, off);
+            if (lane >= off) { Be = __builtin_fmaf(A, Bep, Be); Bt = __builtin_fmaf(A, Btp, Bt); A *= Ap; }
+        }
+        if (lane == 63) { wA[wv] = A; wBe[wv] = Be; wBt[wv] = Bt; }
+        // exclusive values for this lane
+        float Ax = __shfl_up(A, 1), Bex = __shfl_up(Be, 1), Btx = __shfl_up(Bt, 1);
+        if (lane == 0) { Ax = 1.0f; Bex = 0.0f; Btx = 0.0f; }
+        __syncthreads();
+        float ce = cin_e, ct = cin_t;        // carry entering this wave
+        for (int v = 0; v < wv; ++v) { ce = __builtin_fmaf(wA[v], ce, wBe[v]); ct = __builtin_fmaf(wA[v], ct, wBt[v]); }
+        const float le = __builtin_fmaf(Ax, ce, Bex), lt = __builtin_fmaf(Ax, ct, Btx);   // carry entering this lane
+#pragma unroll
+        for (int k = 0; k < DCL; ++k) {
+            if (n0 + k < T) {
+                const float ve = __builtin_fmaf(rp[k + 1], le, ue[k]), vt = __builtin_fmaf(rp[k + 1], lt, ut[k]);
+                se += (double)ve * (double)ve;
+                st += (double)vt * (double)vt;
+            }
+        }
+        if (tid == 255) {                    // carry leaving the chunk
+            carry[0] = __builtin_fmaf(rp[DCL], le, fe);
+            carry[1] = __builtin_fmaf(rp[DCL], lt, ft);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        se += __shfl_down(se, off);
+        st += __shfl_down(st, off);
+    }
+    __shared__ double part[2][4];
+    if (lane == 0) { part[0][wv] = se; part[1][wv] = st; }
+    __syncthreads();
+    if (tid == 0) {
+        out[2 * b + 0] = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
+        out[2 * b + 1] = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
+    }
+}
+
+hipError_t launch_esr_dcpre(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, float R, double *out,
+                            hipStream_t stream)
+{
+    if (B == 0) return hipSuccess;
+    hipLaunchKernelGGL(esr_dcpre_kernel, dim3((unsigned)B), dim3(256), 0, stream, y, t, T, skip, R, out);
+    return hipGetLastError();
+}
+
 }  // namespace ntm

@@ -11,6 +11,8 @@ hipError_t launch_delay(const float *x, const float *d, float *y, int64_t B, int
                         int warmup, float *scratch, int32_t *err_flag, hipStream_t stream);
 hipError_t launch_esr(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, double *out,
                       hipStream_t stream);
+hipError_t launch_esr_dcpre(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, float R, double *out,
+                            hipStream_t stream);
 hipError_t launch_tcn(const float *params, int L, int C, int K, const int *dil, const float *x, float *y, int64_t B,
                       int64_t T, float *scratch, hipStream_t stream);
 }  // namespace ntm
@@ -129,6 +131,17 @@ int ntm_esr_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t s
     if (!y || !t || !out) return fail(NTM_EINVAL, "ntm_esr_sums: null pointer");
     hipError_t e = ntm::launch_esr(y, t, B, T, skip, out, (hipStream_t)stream);
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_esr_sums");
+}
+
+int ntm_esr_dcpre_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, float R, double *out,
+                       void *stream)
+{
+    if (B < 0 || T < 0 || skip < 0 || skip > T) return fail(NTM_EINVAL, "ntm_esr_dcpre_sums: bad size");
+    if (!(R >= 0.0f && R < 1.0f)) return fail(NTM_EINVAL, "ntm_esr_dcpre_sums: R must be in [0,1)");
+    if (B == 0) return NTM_OK;
+    if (!y || !t || !out) return fail(NTM_EINVAL, "ntm_esr_dcpre_sums: null pointer");
+    hipError_t e = ntm::launch_esr_dcpre(y, t, B, T, skip, R, out, (hipStream_t)stream);
+    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_esr_dcpre_sums");
 }
 
 int64_t ntm_tcn_scratch_floats(int64_t B, int64_t T, int C)

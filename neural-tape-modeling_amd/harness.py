@@ -5,7 +5,7 @@ reference's BATCH_SIZE = 1 python loop (code/test-model.py:115,332)."""
 import torch
 
 from . import distributed, weights
-from .model import RNN, DiffDelRNN, esr_sums, ESR_EPS
+from .model import RNN, DiffDelRNN, esr_dcpre_sums, esr_sums, ESR_EPS
 from .utilities import nextpow2, parse_hidden_size, parse_loss, parse_model
 
 
@@ -47,6 +47,9 @@ def compute_loss(model, input, target, d_traj=None, INIT_LEN=1024):
     per_seg = (s[:, 0] / n) / (s[:, 1] / n + ESR_EPS)
     res = distributed.reduce_loss_sums(per_seg, s)
     res["ESR"] = res.pop("mean_segment_loss")
+    # the DCPreESR entry of the loss dict (code/test-model.py:252): same aggregation on DC-blocked signals
+    sd = esr_dcpre_sums(output, target, skip=INIT_LEN)
+    res["DCPreESR"] = distributed.reduce_loss_sums((sd[:, 0] / n) / (sd[:, 1] / n + ESR_EPS))["mean_segment_loss"]
     return res, output
 
 

@@ -288,3 +288,32 @@ class ESRLoss(torch.nn.Module):
         s = esr_sums(output, target).sum(dim=0)
         n = output.numel()
         return ((s[0] / n) / (s[1] / n + ESR_EPS)).float()
+
+
+DC_PRE_R = 0.995
+
+
+@torch.no_grad()
+def esr_dcpre_sums(output, target, skip=0, R=DC_PRE_R):
+    """Per-stream ESR sums of the DC-blocked signals ((1 - z^-1)/(1 - R z^-1), zero state at `skip`)."""
+    y = _as_bt(output, "esr_dcpre_sums")
+    t = _as_bt(target, "esr_dcpre_sums")
+    B, T = y.shape
+    out = torch.empty(B, 2, device=y.device, dtype=torch.float64)
+    rc = _lib.lib().ntm_esr_dcpre_sums(ptr(y), ptr(t), B, T, int(skip), float(R), ptr(out), _lib.current_stream())
+    _lib.check(rc, "ntm_esr_dcpre_sums")
+    return out
+
+
+class DCPreESR(torch.nn.Module):
+    """`DCPreESR(dc_pre=True)` of code/test-model.py:252 / code/train.py:174 on a whole (B,1,T) tensor
+    (GreyBoxDRC ESRLoss, un-vendored: definition re-derived, parity unpinned)."""
+
+    def __init__(self, dc_pre=True, R=DC_PRE_R):
+        super().__init__()
+        self.dc_pre, self.R = dc_pre, R
+
+    def forward(self, output, target):
+        s = (esr_dcpre_sums(output, target, 0, self.R) if self.dc_pre else esr_sums(output, target)).sum(dim=0)
+        n = output.numel()
+        return ((s[0] / n) / (s[1] / n + ESR_EPS)).float()

@@ -46,6 +46,8 @@ def lib():
                                             _f32p, ctypes.c_int, ctypes.c_int]
         _LIB.ntmo_esr_sums.argtypes = [_f32p, _f32p, ctypes.c_int64, ctypes.c_int64,
                                        ctypes.c_int64, _f64p]
+        _LIB.ntmo_esr_dcpre_sums.argtypes = [_f32p, _f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
+                                             ctypes.c_float, _f64p]
         _LIB.ntmo_tcn_forward.argtypes = [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p,
                                           _f32p, _f32p, ctypes.c_int64, ctypes.c_int64]
     return _LIB
@@ -147,6 +149,15 @@ def esr_sums(y, t, skip=0):
 
 
 ESR_EPS = 1e-5
+
+
+def esr_dcpre_sums(y, t, skip=0, R=0.995):
+    """Per-stream ESR sums after the DC blocker (1 - z^-1)/(1 - R z^-1): PARITY UNPINNED (ntm_oracle.c)."""
+    y, t = _c(y), _c(t)
+    B, T = y.shape
+    out = np.empty((B, 2), np.float64)
+    assert lib().ntmo_esr_dcpre_sums(_p(y), _p(t), B, T, skip, R, out.ctypes.data_as(_f64p)) == 0
+    return out
 
 
 def esr_per_segment(y, t, skip=0):

@@ -174,6 +174,34 @@ int ntmo_esr_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t 
 }
 
 /*
+ * DC-pre-emphasised ESR sums (GreyBoxDRC loss_funcs.ESRLoss(dc_pre=True), un-vendored: PARITY UNPINNED).
+ * Both signals pass the DC blocker  H(z) = (1 - z^-1) / (1 - R z^-1)  (zero state at sample `skip`, the
+ * reference cuts INIT_LEN before calling the loss) and the ESR sums are taken on the filtered signals.
+ * Upstream realises H as its impulse response truncated to 2000 taps; R^2000 = 4.4e-5 for R = 0.995, the
+ * recursion below is the untruncated filter.  The filter is linear, so f(t) - f(y) = f(t - y).
+ * out[2b] = sum f(t-y)^2, out[2b+1] = sum f(t)^2 (fp64 sums of the fp32 filter outputs).
+ */
+int ntmo_esr_dcpre_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, float R, double *out)
+{
+    if (skip < 0 || skip > T) return -1;
+    for (int64_t b = 0; b < B; ++b) {
+        double se = 0.0, st = 0.0;
+        float fe = 0.0f, ft = 0.0f, pe = 0.0f, pt = 0.0f;
+        for (int64_t n = skip; n < T; ++n) {
+            const float tv = t[b * T + n], e = tv - y[b * T + n];
+            fe = (e - pe) + R * fe;
+            ft = (tv - pt) + R * ft;
+            pe = e; pt = tv;
+            se += (double)fe * (double)fe;
+            st += (double)ft * (double)ft;
+        }
+        out[b * 2 + 0] = se;
+        out[b * 2 + 1] = st;
+    }
+    return 0;
+}
+
+/*
  * Builder-defined TCN (DESIGN.md "K4"): L causal blocks; block i:
  *   u = causal_dilated_conv1d(in, W_i[C_out,C_in,K], b_i, dilation dil[i])   (zero history)
  *   v = PReLU(u, a_i[C_out])

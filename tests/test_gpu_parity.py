@@ -418,3 +418,18 @@ def test_diagnostic_entry_points_run(ntm):
     assert L.ntm_debug_gru_ablate(P(g.weight_ih_l0), P(g.weight_hh_l0), P(g.bias_ih_l0), P(g.bias_hh_l0), P(o.weight),
                                   P(o.bias), P(x), P(y), B, T, P(h), 4, None) == 0
     torch.cuda.synchronize()
+
+
+def test_esr_dcpre_sums_vs_oracle(ntm):
+    rng = np.random.default_rng(23)
+    for B, T, skip in [(5, 20000, 1024), (2, 100, 0), (3, 4097, 7), (1, 16, 16)]:
+        t = (rng.standard_normal((B, T)) + 0.3).astype(np.float32)       # with a DC offset
+        y = (t + 0.1 * rng.standard_normal((B, T))).astype(np.float32)
+        s = ntm.esr_dcpre_sums(dev(y).unsqueeze(1), dev(t).unsqueeze(1), skip).cpu().numpy()
+        so = oracle.esr_dcpre_sums(y, t, skip)
+        assert np.allclose(s, so, rtol=2e-5, atol=1e-12), (B, T, skip)
+    # the whole-tensor loss object used like `loss_fcn(output, target)` in code/test-model.py:386-388
+    tot = float(ntm.DCPreESR()(dev(y).unsqueeze(1), dev(t).unsqueeze(1)))
+    s0 = oracle.esr_dcpre_sums(y, t, 0).sum(0)
+    n = y.size
+    assert abs(tot - (s0[0] / n) / (s0[1] / n + 1e-5)) < 1e-5 * tot
