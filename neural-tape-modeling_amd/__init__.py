@@ -12,7 +12,7 @@ from .model import (RNN, DCPreESR, DiffDelRNN, ESRLoss, TimeVaryingDelayLine, es
                     esr_per_segment, esr_sums)
 from .tcn import TCN  # noqa: F401
 from .utilities import nextpow2, parse_hidden_size, parse_loss, parse_model  # noqa: F401
-from . import distributed, harness, weights  # noqa: F401
+from . import distributed, feeder, harness, weights  # noqa: F401
 
 __all__ = ["RNN", "DiffDelRNN", "TimeVaryingDelayLine", "TCN", "ESRLoss", "DCPreESR", "esr_dcpre_sums", "esr_sums", "esr_per_segment",
            "parse_hidden_size", "parse_model", "parse_loss", "nextpow2", "weights", "build", "NtmError"]

@@ -433,3 +433,37 @@ def test_esr_dcpre_sums_vs_oracle(ntm):
     s0 = oracle.esr_dcpre_sums(y, t, 0).sum(0)
     n = y.size
     assert abs(tot - (s0[0] / n) / (s0[1] / n + 1e-5)) < 1e-5 * tot
+
+
+def test_cli_loss_over_synthetic_dataset(ntm, tmp_path):
+    """tools/test_model.py (the --COMPUTE_LOSS path of code/test-model.py) on WAV files: feeder -> batched
+    predict -> per-segment ESR / DCPreESR -> mean over segments, against the oracle."""
+    import importlib.util
+    from scipy.io import wavfile
+    spec = importlib.util.spec_from_file_location("ntm_cli", os.path.join(os.path.dirname(os.path.dirname(__file__)),
+                                                                          "tools", "test_model.py"))
+    cli = importlib.util.module_from_spec(spec); spec.loader.exec_module(cli)
+    d = tmp_path / "ToySet" / "Test"
+    d.mkdir(parents=True)
+    rng = np.random.default_rng(12)
+    w = oracle_weights(W_G)
+    L, segs = 4096, []
+    for i in range(2):
+        x = (rng.uniform(-0.5, 0.5, 3 * L + 100) * 32767).astype(np.int16)
+        xf = x.astype(np.float32) / 32768
+        for k in range(3):
+            segs.append(xf[k * L:(k + 1) * L])
+        # target = oracle output of the whole-file stream + a little noise, stored as float32 WAV
+        tf = np.concatenate([oracle.gru_predict(w, s[None])[0][0] for s in segs[-3:]] + [np.zeros(100, np.float32)])
+        tf = (tf + 0.01 * rng.standard_normal(tf.shape)).astype(np.float32)
+        wavfile.write(str(d / f"input_{i}_.wav"), 44100, x)
+        wavfile.write(str(d / f"target_{i}_.wav"), 44100, tf)
+    got = cli.main(["--DATASET_DIR", str(tmp_path / "ToySet"), "--WEIGHTS", W_G, "--SEGMENT_LENGTH", str(L),
+                    "--BATCH_SIZE", "4", "--COMPUTE_LOSS"])
+    f = ntm.feeder.SegmentFeeder(str(tmp_path / "ToySet"), "test", L)
+    X = np.stack([f[i][0][0].numpy() for i in range(len(f))]); Tg = np.stack([f[i][1][0].numpy() for i in range(len(f))])
+    yo, _ = oracle.gru_predict(w, X, threads=4)
+    want = float(np.mean(oracle.esr_per_segment(yo, Tg, 1024)))
+    sd = oracle.esr_dcpre_sums(yo, Tg, 1024); n = L - 1024
+    want_dc = float(np.mean((sd[:, 0] / n) / (sd[:, 1] / n + 1e-5)))
+    assert len(f) == 6 and abs(got["ESR"] - want) < 1e-3 * want and abs(got["DCPreESR"] - want_dc) < 1e-3 * want_dc

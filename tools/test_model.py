@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""The `--COMPUTE_LOSS` path of the reference's evaluation CLI (code/test-model.py:45-85, 192-247, 296-418)
+on the MI355X engine: same UPPER_CASE flags where they apply, batched over segments, shardable over ranks.
+
+    python tools/test_model.py --DATASET_DIR <dir with Test/input_*.wav, target_*.wav> \
+        --WEIGHTS "GRU-HS[64]-L[DCPreESR]-DS[...]_BEST" --SEGMENT_LENGTH 441000 --BATCH_SIZE 64 --COMPUTE_LOSS
+
+Differences: plotting / WAV export / noise / demodulation are out of scope; DiffDelGRU needs
+`trajectory_<id>_*.npy` side-cars (seconds) and `--MAX_DELAY` (seconds) because DelayAnalyzer is not built;
+`--WEIGHTS` names one of the exported checkpoints (ntm_amd.weights.available()) or a directory with best.pth.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ntm_amd  # noqa: E402
+from ntm_amd import distributed as D  # noqa: E402
+from ntm_amd.feeder import SegmentFeeder  # noqa: E402
+from ntm_amd.model import ESR_EPS, esr_dcpre_sums, esr_sums  # noqa: E402
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser(description="Compute the loss of a trained tape model over a dataset.")
+    p.add_argument('--DATASET_DIR', type=str, required=True)
+    p.add_argument('--SUBSET', type=str, default="test")
+    p.add_argument('--WEIGHTS', type=str, required=True)
+    p.add_argument('--SEGMENT_LENGTH', type=int, default=None)
+    p.add_argument('--SYNC', type=float, default=0.0)
+    p.add_argument('--BATCH_SIZE', type=int, default=64)
+    p.add_argument('--MAX_DELAY', type=float, default=0.0, help="seconds (DelayAnalyzer.max_delay of the dataset)")
+    p.add_argument('--COMPUTE_LOSS', action='store_true', default=False)
+    p.add_argument('--KERNEL', type=str, default="auto")
+    a = p.parse_args(argv)
+
+    rank, world, local = D.init_from_env()
+    torch.cuda.set_device(local)
+    feeder = SegmentFeeder(a.DATASET_DIR, subset=a.SUBSET, length=a.SEGMENT_LENGTH, sync=a.SYNC)
+    sd = None
+    if os.path.isdir(a.WEIGHTS):
+        sd = torch.load(os.path.join(a.WEIGHTS, "best.pth"), map_location="cpu")
+    name = os.path.basename(os.path.normpath(a.WEIGHTS))
+    model = ntm_amd.harness.build_model(name, max_delay_seconds=a.MAX_DELAY, fs=feeder.fs, state_dict=sd)
+    model.kernel_variant = a.KERNEL
+    is_dd = isinstance(model, ntm_amd.DiffDelRNN)
+    init_len = ntm_amd.harness.init_len(a.MAX_DELAY, feeder.fs) if a.MAX_DELAY > 0 else 2**10
+    if not a.COMPUTE_LOSS:
+        print(f"{len(feeder)} segments of {feeder.length} samples @ {feeder.fs} Hz; nothing to do without --COMPUTE_LOSS")
+        return {}
+    per = {"ESR": [], "DCPreESR": []}
+    for xin, tgt, dt, _ in feeder.batches(a.BATCH_SIZE, "cuda", rank, world):
+        if is_dd:
+            assert dt is not None, "DiffDelGRU needs trajectory_<id>_*.npy side-cars"
+            out, _ = model.predict(xin, dt * feeder.fs)
+        else:
+            out = model.predict(xin)
+        n = xin.shape[-1] - init_len
+        for key, fn in (("ESR", esr_sums), ("DCPreESR", esr_dcpre_sums)):
+            s = fn(out, tgt, skip=init_len)
+            per[key].append((s[:, 0] / n) / (s[:, 1] / n + ESR_EPS))
+    res = {k: D.reduce_loss_sums(torch.cat(v) if v else torch.zeros(0, device="cuda", dtype=torch.float64))
+           for k, v in per.items()}
+    if rank == 0:
+        print("\n===== Stats: =====")
+        print(f"Model:      {name}\nDataset:    {os.path.basename(os.path.normpath(a.DATASET_DIR))}\nSubset:     {a.SUBSET}")
+        print(f"Segments:   {res['ESR']['segments']}\n")
+        for k, v in res.items():
+            print(f"{k.ljust(9)}: {v['mean_segment_loss']:.6f}")
+        print("\n==================")
+    return {k: v["mean_segment_loss"] for k, v in res.items()}
+
+
+if __name__ == "__main__":
+    main()
