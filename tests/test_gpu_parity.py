@@ -467,3 +467,18 @@ def test_cli_loss_over_synthetic_dataset(ntm, tmp_path):
     sd = oracle.esr_dcpre_sums(yo, Tg, 1024); n = L - 1024
     want_dc = float(np.mean((sd[:, 0] / n) / (sd[:, 1] / n + 1e-5)))
     assert len(f) == 6 and abs(got["ESR"] - want) < 1e-3 * want and abs(got["DCPreESR"] - want_dc) < 1e-3 * want_dc
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_saturating_inputs(ntm, variant):
+    """|x| up to 100 drives every gate into saturation (2^x -> inf / 0 inside sigmoid and tanh): the fast
+    exp2/rcp forms must still land on the oracle, with no NaN."""
+    rng = np.random.default_rng(17)
+    x = (rng.uniform(-1, 1, (6, 400)) * np.array([[1], [10], [100], [100], [1e-3], [0]])).astype(np.float32)
+    yo, ho = oracle.gru_forward(oracle_weights(W_G), x)
+    m = make_rnn(ntm, W_G, variant)
+    m.initialize_hidden()
+    y = m(dev(x).unsqueeze(1)).cpu().numpy()[:, 0]
+    assert np.isfinite(y).all()
+    assert np.abs(y - yo).max() < TOL
+    assert np.abs(m.hidden.cpu().numpy()[0] - ho).max() < TOL
