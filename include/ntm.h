@@ -38,6 +38,7 @@ extern "C" {
 #define NTM_GRU_MFMA 1  /* 16 streams / workgroup, 4 waves, v_mfma_f32_16x16x4_f32, h in LDS */
 #define NTM_GRU_VALU 2  /* 2 streams / wavefront, W_hh in VGPRs, h broadcast through LDS     */
 #define NTM_GRU_MFMA2 3 /* as MFMA, own-quarter-first step order: LDS exchange hidden by MFMAs */
+#define NTM_GRU_MFMA3 5 /* exact fp32 hybrid: MFMA waves + partner VALU waves on the same SIMDs       */
 #define NTM_GRU_F16X3 4 /* OPT-IN: MFMA2 with W.h as three fp16 hi/lo products, fp32 accumulate  */
 
 /* ABI version of this header; bumped on any signature change. */

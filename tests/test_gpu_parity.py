@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 W_G = "GRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE]_BEST"
 W_D = "DiffDelGRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE_WOWFLUTTER]_BEST"
-VARIANTS = ["mfma2", "mfma", "valu", "f16x3"]
+VARIANTS = ["mfma2", "mfma", "valu", "f16x3", "mfma3"]
 
 
 @pytest.fixture(scope="module")
@@ -164,7 +164,7 @@ def test_variants_agree_and_raw_abi_strides(ntm):
     xh = rng.uniform(-0.5, 0.5, (B, XS)).astype(np.float32)
     x = dev(xh)
     outs = []
-    for variant in (1, 2, 3, 4):
+    for variant in (1, 2, 3, 4, 5):
         y = torch.full((B, YS), 7.0, device="cuda")
         rc = L.ntm_gru_forward_ex(*[ctypes.c_void_p(sd[k].data_ptr()) for k in
                                     ["GRU.weight_ih_l0", "GRU.weight_hh_l0", "GRU.bias_ih_l0", "GRU.bias_hh_l0",
