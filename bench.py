@@ -120,6 +120,14 @@ def side_workload(a):
         model = ntm_amd.TCN().to(dev)
         run = lambda: model(x)                                               # noqa: E731
         name, bytes_per_sample = "TCN 4x(k13, dil 1/10/100/1000, 32 ch) seeded weights", 8
+    # stream 0 against the CPU oracle (whole sequence): the side workloads get a parity check of their own
+    import oracle
+    if a.workload == "diffdel":
+        w_or = oracle.Weights.from_state_dict({k: v.numpy() for k, v in weights.load_state_dict(weights.W_DIFFDEL).items()})
+        ref0 = oracle.diffdel_predict(w_or, x[:1, 0].cpu().numpy(), d[:1, 0].cpu().numpy(), model.max_delay)[0][0]
+    else:
+        ref0 = oracle.tcn_forward(model.packed_params().cpu().numpy(), len(model.dilations), model.channels,
+                                  model.kernel_size, model.dilations, x[:1, 0].cpu().numpy())[0]
     for _ in range(max(a.warmup, 1)):
         y0 = run()
     torch.cuda.synchronize()
@@ -135,7 +143,8 @@ def side_workload(a):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{name}, {B} segments x {T} samples fp32"},
         "device_ms_per_step": float(np.mean(ms)), "bytes_per_sample": bytes_per_sample,
-        "checks": {"deterministic": bool(torch.equal(y, y0))}}))
+        "checks": {"deterministic": bool(torch.equal(y, y0)),
+                   "stream0_vs_oracle_max_abs": float(np.abs(y[0, 0].cpu().numpy() - ref0).max())}}))
 
 
 def main():
