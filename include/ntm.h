@@ -138,6 +138,15 @@ int ntm_esr_dcpre_sums(const float *y, const float *t, int64_t B, int64_t T, int
                        double *out, void *stream);
 
 /*
+ * "Next" row N4: replaces Tape.H_mag, code/tape.py:516-551 (Jiles-Atherton hysteresis, RK4, fp64) of the
+ * reference's white-box tape simulator.  H, M: [B,N] fp64 device, contiguous (oversampled rate);
+ * state [B,3] fp64 device = (M_prev, H_prev, Hprime_prev), read and updated (zeros initially, :303-309);
+ * Ts = 1/(fs*oversampling); params5 is a HOST array {Ms, A, alpha, K, c} (code/tape.py:251-256).
+ */
+int ntm_tape_hmag(const double *H, double *M, int64_t B, int64_t N, double *state, double Ts,
+                  const double *params5, void *stream);
+
+/*
  * Builder-defined causal dilated-Conv1d TCN (BASELINE.json config 4; the reference has no TCN:
  * code/micro_tcn is an empty submodule).  L causal blocks  out = PReLU(conv_dilated(in)) + conv1x1(in),
  * then a 1x1 conv to one channel.  params (device), block after block:

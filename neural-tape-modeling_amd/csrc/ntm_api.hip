@@ -13,6 +13,8 @@ hipError_t launch_esr(const float *y, const float *t, int64_t B, int64_t T, int6
                       hipStream_t stream);
 hipError_t launch_esr_dcpre(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, float R, double *out,
                             hipStream_t stream);
+hipError_t launch_tape_hmag(const double *H, double *M, int64_t B, int64_t N, double *state, double Ts, const double *par,
+                            hipStream_t stream);
 hipError_t launch_tcn(const float *params, int L, int C, int K, const int *dil, const float *x, float *y, int64_t B,
                       int64_t T, float *scratch, hipStream_t stream);
 }  // namespace ntm
@@ -143,6 +145,16 @@ int ntm_esr_dcpre_sums(const float *y, const float *t, int64_t B, int64_t T, int
     if (!y || !t || !out) return fail(NTM_EINVAL, "ntm_esr_dcpre_sums: null pointer");
     hipError_t e = ntm::launch_esr_dcpre(y, t, B, T, skip, R, out, (hipStream_t)stream);
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_esr_dcpre_sums");
+}
+
+int ntm_tape_hmag(const double *H, double *M, int64_t B, int64_t N, double *state, double Ts, const double *params5,
+                  void *stream)
+{
+    if (B < 0 || N < 0 || !(Ts > 0.0)) return fail(NTM_EINVAL, "ntm_tape_hmag: bad size or Ts");
+    if (B == 0 || N == 0) return NTM_OK;
+    if (!H || !M || !state || !params5) return fail(NTM_EINVAL, "ntm_tape_hmag: null pointer");
+    hipError_t e = ntm::launch_tape_hmag(H, M, B, N, state, Ts, params5, (hipStream_t)stream);
+    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_tape_hmag");
 }
 
 int64_t ntm_tcn_scratch_floats(int64_t B, int64_t T, int C)

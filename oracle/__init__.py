@@ -48,6 +48,7 @@ def lib():
                                        ctypes.c_int64, _f64p]
         _LIB.ntmo_esr_dcpre_sums.argtypes = [_f32p, _f32p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64,
                                              ctypes.c_float, _f64p]
+        _LIB.ntmo_tape_hmag.argtypes = [_f64p, _f64p, ctypes.c_int64, ctypes.c_int64, _f64p, ctypes.c_double, _f64p]
         _LIB.ntmo_tcn_forward.argtypes = [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p,
                                           _f32p, _f32p, ctypes.c_int64, ctypes.c_int64]
     return _LIB
@@ -165,6 +166,21 @@ def esr_per_segment(y, t, skip=0):
     s = esr_sums(y, t, skip)
     n = y.shape[1] - skip
     return (s[:, 0] / n) / (s[:, 1] / n + ESR_EPS)
+
+
+TAPE_PARAMS = (1.6e6, 1.1e3, 1.6e-3, 4.0e2, 1.7e-1)      # Ms, A, alpha, K, c  (code/tape.py:251-256)
+
+
+def tape_hmag(H, state=None, Ts=1.0 / (48000 * 16), params=TAPE_PARAMS):
+    """Tape.H_mag, code/tape.py:516-551.  H [B,N] f64 -> (M [B,N], state [B,3] = M_prev,H_prev,Hprime_prev)."""
+    H = np.ascontiguousarray(H, dtype=np.float64)
+    B, N = H.shape
+    state = np.zeros((B, 3)) if state is None else np.ascontiguousarray(state, dtype=np.float64).copy()
+    M = np.empty_like(H)
+    par = np.asarray(params, dtype=np.float64)
+    d = lambda a: a.ctypes.data_as(_f64p)                                                    # noqa: E731
+    assert lib().ntmo_tape_hmag(d(H), d(M), B, N, d(state), Ts, d(par)) == 0
+    return M, state
 
 
 def tcn_forward(params, L, C, K, dil, x):

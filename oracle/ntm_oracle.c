@@ -202,6 +202,53 @@ int ntmo_esr_dcpre_sums(const float *y, const float *t, int64_t B, int64_t T, in
 }
 
 /*
+ * Jiles-Atherton magnetisation stage of the reference's white-box tape simulator ("next" row N4):
+ * code/tape.py:516-551 (Tape.H_mag: trapezoidal dH/dt, RK4, clamp to +-Ms) with code/tape.py:587-635
+ * (Tape._f), fp64, operation for operation -- including the reference's L'(.) evaluated on L(Q) instead of
+ * on Q (:598-603).  PINNED by tests/golden/g9_tape_hmag.npz (generated from the reference's own H_mag).
+ * H, M [B,N]; state [B,3] = (M_prev, H_prev, Hprime_prev) in/out; par = {Ms, A, alpha, K, c}.
+ */
+static double ja_f(double Mn, double Hn, double Hp, const double *par)
+{
+    const double Ms = par[0], A = par[1], alpha = par[2], K = par[3], c = par[4];
+    const double Q = (Hn + alpha * Mn) / A;
+    const double LQ = fabs(Q) > 1e-4 ? (1.0 / tanh(Q)) - 1.0 / Q : Q / 3.0;
+    double LpQ;
+    if (fabs(LQ) > 1e-4) { const double ct = 1.0 / tanh(LQ); LpQ = 1.0 / (LQ * LQ) - ct * ct + 1.0; } else LpQ = 1.0 / 3.0;
+    const double M_diff = Ms * LQ - Mn;
+    const double dS = Hp > 0.0 ? 1.0 : -1.0;
+    const double sgn = M_diff > 0.0 ? 1.0 : (M_diff < 0.0 ? -1.0 : 0.0);
+    const double dM = (dS == sgn) ? 1.0 : 0.0;
+    const double t1n = (1.0 - c) * dM * M_diff;
+    const double t1d = (1.0 - c) * dS * K - alpha * M_diff;
+    const double t1 = (t1n / t1d) * Hp;
+    const double t2 = c * (Ms / A) * Hp * LpQ;
+    const double t3 = 1.0 - c * alpha * (Ms / A) * LpQ;
+    return (t1 + t2) / t3;
+}
+
+int ntmo_tape_hmag(const double *H, double *M, int64_t B, int64_t N, double *state, double Ts, const double *par)
+{
+    for (int64_t b = 0; b < B; ++b) {
+        double Mp = state[3 * b], Hpv = state[3 * b + 1], Hpp = state[3 * b + 2];
+        for (int64_t n = 0; n < N; ++n) {
+            const double Hn = H[b * N + n];
+            const double Hprime = 2.0 * (Hn - Hpv) / Ts - Hpp;
+            const double k1 = Ts * ja_f(Mp, Hpv, Hpp, par);
+            const double k2 = Ts * ja_f(Mp + k1 / 2.0, (Hn + Hpv) / 2.0, (Hprime + Hpp) / 2.0, par);
+            const double k3 = Ts * ja_f(Mp + k2 / 2.0, (Hn + Hpv) / 2.0, (Hprime + Hpp) / 2.0, par);
+            const double k4 = Ts * ja_f(Mp + k3, Hn, Hprime, par);
+            double m = Mp + k1 / 6.0 + k2 / 3.0 + k3 / 3.0 + k4 / 6.0;
+            m = m < -par[0] ? -par[0] : (m > par[0] ? par[0] : m);
+            M[b * N + n] = m;
+            Hpv = Hn; Hpp = Hprime; Mp = m;
+        }
+        state[3 * b] = Mp; state[3 * b + 1] = Hpv; state[3 * b + 2] = Hpp;
+    }
+    return 0;
+}
+
+/*
  * Builder-defined TCN (DESIGN.md "K4"): L causal blocks; block i:
  *   u = causal_dilated_conv1d(in, W_i[C_out,C_in,K], b_i, dilation dil[i])   (zero history)
  *   v = PReLU(u, a_i[C_out])

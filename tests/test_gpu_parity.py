@@ -482,3 +482,22 @@ def test_saturating_inputs(ntm, variant):
     assert np.isfinite(y).all()
     assert np.abs(y - yo).max() < TOL
     assert np.abs(m.hidden.cpu().numpy()[0] - ho).max() < TOL
+
+
+def test_g9_tape_hmag(ntm):
+    """N4: Jiles-Atherton RK4 stage against the reference's own Tape.H_mag output (fp64), state carried."""
+    g = load("g9_tape_hmag.npz")
+    H, split = g["H"], int(g["split"])
+    tp = ntm.TapeMagnetization(batch_size=H.shape[0])
+    assert abs(tp.Ts_OS - float(g["Ts_OS"])) < 1e-18
+    M = torch.cat([tp.H_mag(torch.from_numpy(H[:, :split]).cuda()), tp.H_mag(torch.from_numpy(H[:, split:]).cuda())], 1)
+    scale = tp.TAPE_Ms
+    assert np.abs(M.cpu().numpy() - g["M"]).max() < 1e-6 * scale
+    assert np.abs(tp.M_prev.cpu().numpy() - g["M_prev"]).max() < 1e-6 * scale
+    assert np.allclose(tp.H_prev.cpu().numpy(), g["H_prev"]) and np.allclose(tp.Hprime_prev.cpu().numpy(), g["Hprime_prev"])
+    # a batch that does not fill a 64-stream block, against the oracle
+    rng = np.random.default_rng(1)
+    H2 = 8000.0 * rng.standard_normal((70, 300)).cumsum(1) / 20
+    Mo, _ = oracle.tape_hmag(H2)
+    tp2 = ntm.TapeMagnetization(batch_size=70)
+    assert np.abs(tp2.H_mag(torch.from_numpy(H2).cuda()).cpu().numpy() - Mo).max() < 1e-6 * scale

@@ -151,3 +151,15 @@ def test_tcn_oracle_vs_torch_conv1d():
     want = F.conv1d(a, m.out_weight, m.out_bias)[:, 0, :].numpy()
     assert np.abs(y - want).max() < 2e-5
     assert m.receptive_field == 1 + 12 * 40
+
+
+def test_g9_tape_hmag_jiles_atherton():
+    """N4: the oracle's RK4 Jiles-Atherton stage against the reference's own Tape.H_mag (fp64)."""
+    g = load("g9_tape_hmag.npz")
+    H, split = g["H"], int(g["split"])
+    M1, st = oracle.tape_hmag(H[:, :split], None, float(g["Ts_OS"]), g["params"])
+    M2, st = oracle.tape_hmag(H[:, split:], st, float(g["Ts_OS"]), g["params"])
+    M = np.concatenate([M1, M2], 1)
+    scale = float(g["params"][0])
+    assert np.abs(M - g["M"]).max() < 1e-7 * scale
+    assert np.abs(st[:, 0] - g["M_prev"]).max() < 1e-7 * scale and np.allclose(st[:, 1], g["H_prev"])
