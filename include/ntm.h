@@ -138,6 +138,21 @@ int ntm_esr_dcpre_sums(const float *y, const float *t, int64_t B, int64_t T, int
                        double *out, void *stream);
 
 /*
+ * "Next" row N1: per-stream sums of the multi-resolution STFT loss of code/test-model.py:25,253
+ * (`MultiResolutionSTFTLoss()` of the un-vendored auraloss submodule: parity unpinned by the reference; the
+ * arithmetic is pinned to torch.stft by tests/golden/g10).  For ONE resolution, over samples [skip, T) of each
+ * stream:  X = stft(x, n_fft, hop, win_length, periodic Hann, centred, reflect padding),
+ * mag = sqrt(max(re^2 + im^2, power_eps)), and with P = 4 * chunks partial rows per stream
+ *   out[(b*P + p)*4 + 0..3] = sum (mag_t - mag_y)^2 | sum mag_t^2 | sum |ln mag_y - ln mag_t| | sum |mag_y - mag_t|
+ * (fp64, device; the caller adds the P rows of a stream).  y = prediction, t = target, [B,T] contiguous.
+ * n_fft in {256, 512, 1024, 2048}; 0 < win_length <= n_fft; T - skip > n_fft/2; power_eps > 0 (auraloss: 1e-8);
+ * chunks >= 1 splits the frames of a stream over that many workgroups.  There are 1 + (T-skip)/hop frames
+ * of n_fft/2 + 1 bins.
+ */
+int ntm_stft_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int n_fft, int hop,
+                  int win_length, float power_eps, int chunks, double *out, void *stream);
+
+/*
  * "Next" row N4: replaces Tape.H_mag, code/tape.py:516-551 (Jiles-Atherton hysteresis, RK4, fp64) of the
  * reference's white-box tape simulator.  H, M: [B,N] fp64 device, contiguous (oversampled rate);
  * state [B,3] fp64 device = (M_prev, H_prev, Hprime_prev), read and updated (zeros initially, :303-309);

@@ -13,6 +13,8 @@ hipError_t launch_esr(const float *y, const float *t, int64_t B, int64_t T, int6
                       hipStream_t stream);
 hipError_t launch_esr_dcpre(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, float R, double *out,
                             hipStream_t stream);
+hipError_t launch_stft_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int n_fft, int hop,
+                            int win, float eps, int chunks, double *out, hipStream_t stream);
 hipError_t launch_tape_hmag(const double *H, double *M, int64_t B, int64_t N, double *state, double Ts, const double *par,
                             hipStream_t stream);
 hipError_t launch_tcn(const float *params, int L, int C, int K, const int *dil, const float *x, float *y, int64_t B,
@@ -145,6 +147,23 @@ int ntm_esr_dcpre_sums(const float *y, const float *t, int64_t B, int64_t T, int
     if (!y || !t || !out) return fail(NTM_EINVAL, "ntm_esr_dcpre_sums: null pointer");
     hipError_t e = ntm::launch_esr_dcpre(y, t, B, T, skip, R, out, (hipStream_t)stream);
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_esr_dcpre_sums");
+}
+
+int ntm_stft_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int n_fft, int hop, int win_length,
+                  float power_eps, int chunks, double *out, void *stream)
+{
+    if (B < 0 || T < 0 || skip < 0 || skip > T) return fail(NTM_EINVAL, "ntm_stft_sums: bad size");
+    if (n_fft != 256 && n_fft != 512 && n_fft != 1024 && n_fft != 2048)
+        return fail(NTM_EINVAL, "ntm_stft_sums: n_fft must be 256, 512, 1024 or 2048");
+    if (hop <= 0 || win_length <= 0 || win_length > n_fft) return fail(NTM_EINVAL, "ntm_stft_sums: bad hop or win_length");
+    if (!(power_eps > 0.0f)) return fail(NTM_EINVAL, "ntm_stft_sums: power_eps must be positive");
+    if (chunks < 1 || B * (int64_t)chunks > 0x7fffffff) return fail(NTM_EINVAL, "ntm_stft_sums: bad chunks");
+    if (B == 0) return NTM_OK;
+    if (T - skip <= n_fft / 2) return fail(NTM_EINVAL, "ntm_stft_sums: reflect padding needs T - skip > n_fft/2");
+    if ((T - skip) / hop + 1 > 0x7fffffff) return fail(NTM_EINVAL, "ntm_stft_sums: too many frames");
+    if (!y || !t || !out) return fail(NTM_EINVAL, "ntm_stft_sums: null pointer");
+    hipError_t e = ntm::launch_stft_sums(y, t, B, T, skip, n_fft, hop, win_length, power_eps, chunks, out, (hipStream_t)stream);
+    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_stft_sums");
 }
 
 int ntm_tape_hmag(const double *H, double *M, int64_t B, int64_t N, double *state, double Ts, const double *params5,

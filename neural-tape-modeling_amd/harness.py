@@ -5,7 +5,7 @@ reference's BATCH_SIZE = 1 python loop (code/test-model.py:115,332)."""
 import torch
 
 from . import distributed, weights
-from .model import RNN, DiffDelRNN, esr_dcpre_sums, esr_sums, ESR_EPS
+from .model import RNN, DiffDelRNN, MRSTFTLoss, esr_dcpre_sums, esr_sums, ESR_EPS
 from .utilities import nextpow2, parse_hidden_size, parse_loss, parse_model
 
 
@@ -50,6 +50,9 @@ def compute_loss(model, input, target, d_traj=None, INIT_LEN=1024):
     # the DCPreESR entry of the loss dict (code/test-model.py:252): same aggregation on DC-blocked signals
     sd = esr_dcpre_sums(output, target, skip=INIT_LEN)
     res["DCPreESR"] = distributed.reduce_loss_sums((sd[:, 0] / n) / (sd[:, 1] / n + ESR_EPS))["mean_segment_loss"]
+    # the MultiSTFT entry (code/test-model.py:253), when the segments are long enough for its largest frame
+    if n > 1024:
+        res["MultiSTFT"] = distributed.reduce_loss_sums(MRSTFTLoss().per_segment(output, target, skip=INIT_LEN))["mean_segment_loss"]
     return res, output
 
 

@@ -5,7 +5,8 @@ The product (neural-tape-modeling_amd + libntm.so) never does; it fails loudly w
 library instead of falling back to anything here.
 
 Parity status: pinned by tests/golden/g1..g8 (generated from the reference by
-tools/make_goldens.py); ESR and the TCN are "parity unpinned" (no reference source exists).
+tools/make_goldens.py); ESR, the MR-STFT loss and the TCN are "parity unpinned" (no reference source
+exists; the MR-STFT restatement is pinned to torch.stft by g10).
 
 Three layers, all restating code/model.py of the reference:
   * C (ntm_oracle.c via ctypes)  -- fast enough for 16x8192 / 1x65536 cases and the CPU baseline
@@ -166,6 +167,54 @@ def esr_per_segment(y, t, skip=0):
     s = esr_sums(y, t, skip)
     n = y.shape[1] - skip
     return (s[:, 0] / n) / (s[:, 1] / n + ESR_EPS)
+
+
+MRSTFT_RESOLUTIONS = ((1024, 120, 600), (2048, 240, 1200), (512, 50, 240))   # (n_fft, hop, win_length)
+STFT_EPS = 1e-8
+
+
+def stft_sums(y, t, skip=0, n_fft=1024, hop=120, win_length=600, eps=STFT_EPS):
+    """Per-stream sums of auraloss.freq.STFTLoss (un-vendored submodule of the reference, imported at
+    code/test-model.py:25 and instantiated with its defaults at :253) -- PARITY UNPINNED by the reference,
+    pinned to torch.stft by tests/golden/g10 (tools/make_goldens_stft.py).  fp64 numpy restatement of
+      X = torch.stft(x, n_fft, hop, win_length, hann_window(win_length))   (center, reflect padding, the window
+                                                                            zero-padded to n_fft on both sides)
+      mag = sqrt(clamp(re^2 + im^2, min=eps))
+    over samples [skip, T) of each stream.  Returns [B,4] float64:
+      sum (mag_t - mag_y)^2 | sum mag_t^2 | sum |ln mag_y - ln mag_t| | sum |mag_y - mag_t|
+    and the number of (bin, frame) cells per stream."""
+    y = np.asarray(y, np.float64)[:, skip:]
+    t = np.asarray(t, np.float64)[:, skip:]
+    B, L = y.shape
+    assert L > n_fft // 2, "reflect padding needs more than n_fft/2 samples"
+    n = np.arange(win_length)
+    win = np.zeros(n_fft)
+    left = (n_fft - win_length) // 2
+    win[left:left + win_length] = 0.5 - 0.5 * np.cos(2 * np.pi * n / win_length)      # periodic Hann
+    n_frames = 1 + L // hop
+    idx = np.arange(n_frames)[:, None] * hop + np.arange(n_fft)[None, :]
+
+    def mag(x):
+        xp = np.pad(x, ((0, 0), (n_fft // 2, n_fft // 2)), mode="reflect")
+        X = np.fft.rfft(xp[:, idx] * win, axis=-1)                                       # [B, frames, bins]
+        return np.sqrt(np.maximum(X.real ** 2 + X.imag ** 2, eps))
+
+    out = np.empty((B, 4))
+    for b in range(B):                      # stream by stream: bounded memory
+        my, mt = mag(y[b:b + 1]), mag(t[b:b + 1])
+        out[b] = [((mt - my) ** 2).sum(), (mt ** 2).sum(), np.abs(np.log(my) - np.log(mt)).sum(), np.abs(my - mt).sum()]
+    return out, n_frames * (n_fft // 2 + 1)
+
+
+def mrstft_per_segment(y, t, skip=0, resolutions=MRSTFT_RESOLUTIONS):
+    """auraloss MultiResolutionSTFTLoss() defaults (w_sc = w_log_mag = 1, w_lin_mag = w_phs = 0), evaluated
+    per stream as the harness does (code/test-model.py:386-398): mean over resolutions of
+    ||mag_t - mag_y||_F / ||mag_t||_F + mean |ln mag_y - ln mag_t|."""
+    total = 0.0
+    for n_fft, hop, win in resolutions:
+        s, cells = stft_sums(y, t, skip, n_fft, hop, win)
+        total = total + np.sqrt(s[:, 0]) / np.sqrt(s[:, 1]) + s[:, 2] / cells
+    return total / len(resolutions)
 
 
 TAPE_PARAMS = (1.6e6, 1.1e3, 1.6e-3, 4.0e2, 1.7e-1)      # Ms, A, alpha, K, c  (code/tape.py:251-256)

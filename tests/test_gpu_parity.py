@@ -501,3 +501,70 @@ def test_g9_tape_hmag(ntm):
     Mo, _ = oracle.tape_hmag(H2)
     tp2 = ntm.TapeMagnetization(batch_size=70)
     assert np.abs(tp2.H_mag(torch.from_numpy(H2).cuda()).cpu().numpy() - Mo).max() < 1e-6 * scale
+
+
+STFT_RES = [(1024, 120, 600), (2048, 240, 1200), (512, 50, 240), (256, 64, 256), (512, 128, 500)]
+
+
+@pytest.mark.parametrize("res", STFT_RES)
+def test_stft_sums_vs_oracle(ntm, res):
+    """N1: one STFT resolution (FFT kernel, fp32) against the fp64 oracle on the g10 pairs; the last two
+    resolutions are not auraloss defaults (n_fft 256; an even window that is not centred on a 64-lane boundary)."""
+    g = load("g10_mrstft.npz")
+    n_fft, hop, win = res
+    for skip in (int(g["skip"]), 0, 8192 - n_fft // 2 - 1):
+        s, cells = ntm.stft_sums(dev(g["pred"]).unsqueeze(1), dev(g["targ"]).unsqueeze(1), skip, n_fft, hop, win)
+        so, cells_o = oracle.stft_sums(g["pred"], g["targ"], skip, n_fft, hop, win)
+        assert cells == cells_o
+        assert np.allclose(s.cpu().numpy(), so, rtol=1e-4), (res, skip, s.cpu().numpy() / so - 1)
+
+
+def test_g10_mrstft_loss(ntm):
+    """MultiResolutionSTFTLoss() per segment against torch.stft + the auraloss formula (golden g10), and the
+    whole-batch form against the oracle's sums."""
+    g = load("g10_mrstft.npz")
+    skip = int(g["skip"])
+    y, t = dev(g["pred"]).unsqueeze(1), dev(g["targ"]).unsqueeze(1)
+    loss = ntm.MRSTFTLoss()
+    per = loss.per_segment(y, t, skip).cpu().numpy()
+    assert np.allclose(per, g["loss"], rtol=1e-4), per / g["loss"] - 1
+    whole, cells_all = 0.0, 0
+    for n_fft, hop, win in oracle.MRSTFT_RESOLUTIONS:
+        so, cells = oracle.stft_sums(g["pred"], g["targ"], 0, n_fft, hop, win)
+        so = so.sum(0)
+        whole += np.sqrt(so[0] / so[1]) + so[2] / (cells * len(g["pred"]))
+    assert abs(float(loss(y, t)) - whole / 3) < 1e-4 * whole / 3
+    # the linear-magnitude weight (off by default upstream)
+    lin = ntm.MRSTFTLoss(w_sc=0.0, w_log_mag=0.0, w_lin_mag=1.0).per_segment(y, t, skip).cpu().numpy()
+    assert np.allclose(lin, g["terms"][:, :, 2].mean(1), rtol=1e-4)
+
+
+def test_stft_sums_many_streams_chunking(ntm):
+    """Chunked launches (frames of a stream split over workgroups) and single-chunk launches give the same
+    sums; identical signals give (numerically) zero distance; silence hits the eps clamp on both sides."""
+    rng = np.random.default_rng(5)
+    B, T = 3, 40000
+    t = (0.3 * rng.standard_normal((B, T))).astype(np.float32)
+    y = (t + 0.01 * rng.standard_normal((B, T))).astype(np.float32)
+    y[2] = t[2]
+    t[1, 10000:30000] = 0.0; y[1, 10000:30000] = 0.0
+    s, cells = ntm.stft_sums(dev(y).unsqueeze(1), dev(t).unsqueeze(1), 100)          # B = 3 -> many chunks
+    so, _ = oracle.stft_sums(y, t, 100)
+    assert np.allclose(s.cpu().numpy()[:2], so[:2], rtol=1e-4)
+    # identical signals: the pair shares one complex FFT, so the distance is rounding noise rather than exactly 0
+    s2 = s.cpu().numpy()[2]
+    assert s2[0] / s2[1] < 1e-12 and s2[2] / cells < 1e-5 and abs(s2[1] / so[2, 1] - 1) < 1e-4
+    yy, tt = np.tile(y, (1000, 1)), np.tile(t, (1000, 1))                             # B = 3000 -> one chunk each
+    s1, _ = ntm.stft_sums(dev(yy).unsqueeze(1), dev(tt).unsqueeze(1), 100)
+    assert np.allclose(s1.cpu().numpy()[:3], s.cpu().numpy(), rtol=1e-9)
+    assert (s1.cpu().numpy()[3:6] == s1.cpu().numpy()[:3]).all()
+
+
+def test_stft_sums_errors(ntm):
+    y = dev(np.zeros((2, 4096), np.float32)).unsqueeze(1)
+    with pytest.raises(ntm.NtmError):
+        ntm.stft_sums(y, y, 0, 1000, 120, 600)            # n_fft not a supported power of two
+    with pytest.raises(ntm.NtmError):
+        ntm.stft_sums(y, y, 4096 - 512, 1024, 120, 600)   # T - skip <= n_fft/2: reflect padding impossible
+    with pytest.raises(ntm.NtmError):
+        ntm.stft_sums(y, y, 0, 1024, 120, 1025)           # window longer than the frame

@@ -163,3 +163,18 @@ def test_g9_tape_hmag_jiles_atherton():
     scale = float(g["params"][0])
     assert np.abs(M - g["M"]).max() < 1e-7 * scale
     assert np.abs(st[:, 0] - g["M_prev"]).max() < 1e-7 * scale and np.allclose(st[:, 1], g["H_prev"])
+
+
+def test_g10_mrstft_against_torch_stft():
+    """N1: the fp64 STFT-loss restatement against torch.stft + the auraloss formula evaluated here in fp32
+    (tools/make_goldens_stft.py): spectral convergence, log-magnitude and linear-magnitude terms per
+    resolution, and the multi-resolution loss per segment."""
+    g = load("g10_mrstft.npz")
+    skip = int(g["skip"])
+    for r, (n_fft, hop, win) in enumerate(g["res"]):
+        s, cells = oracle.stft_sums(g["pred"], g["targ"], skip, int(n_fft), int(hop), int(win))
+        assert cells == (1 + (g["pred"].shape[1] - skip) // int(hop)) * (int(n_fft) // 2 + 1)
+        assert np.allclose(np.sqrt(s[:, 0] / s[:, 1]), g["terms"][:, r, 0], rtol=2e-5)
+        assert np.allclose(s[:, 2] / cells, g["terms"][:, r, 1], rtol=2e-5)
+        assert np.allclose(s[:, 3] / cells, g["terms"][:, r, 2], rtol=2e-5)
+    assert np.allclose(oracle.mrstft_per_segment(g["pred"], g["targ"], skip), g["loss"], rtol=1e-5)
