@@ -153,6 +153,17 @@ int ntm_stft_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t 
                   int win_length, float power_eps, int chunks, double *out, void *stream);
 
 /*
+ * "Next" row N3: DelayAnalyzer.demodulate, code/utilities/utilities.py:408-465 -- removes the time-varying
+ * delay of a recording using the pulse indices of its pilot channel.  x, out: [C,N] fp32 device (out must not
+ * alias x); y_idx [P] int64 device = output pulse indices (strictly increasing, P >= 2);
+ * period = int(mean(diff(input pulse indices))) and shift = y_idx[0] - x_idx[0] are computed by the caller from
+ * the INPUT pulse indices (:436, :458); scratch holds N doubles.  Interpolation runs in fp64 with scipy's
+ * formulas, results are rounded to fp32 on store.
+ */
+int ntm_demodulate(const float *x, float *out, int C, int64_t N, const int64_t *y_idx, int P, int64_t period,
+                   int64_t shift, double *scratch, void *stream);
+
+/*
  * "Next" row N4: replaces Tape.H_mag, code/tape.py:516-551 (Jiles-Atherton hysteresis, RK4, fp64) of the
  * reference's white-box tape simulator.  H, M: [B,N] fp64 device, contiguous (oversampled rate);
  * state [B,3] fp64 device = (M_prev, H_prev, Hprime_prev), read and updated (zeros initially, :303-309);

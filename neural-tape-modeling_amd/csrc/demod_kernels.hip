@@ -1,0 +1,76 @@
+// "Next" row N3: DelayAnalyzer.demodulate, code/utilities/utilities.py:408-465 -- undo the time-varying delay of a
+// (C, N) recording from the pulse indices of its pilot train.  Two piecewise-linear maps, both evaluated with
+// the formulas of scipy.interpolate.interp1d(kind='linear') in fp64 so that the result matches the reference's
+// numpy/scipy code to the last bit before the final fp32 store:
+//   y_hat[j] = f(j),  f through the knots (y_idx[i] -> y_idx[0] + i*period), extrapolated          (:441-447)
+//   dem[t]   = g(t),  g through the knots (y_hat[j] -> x[:, j]); below the first knot x[:, 0], above the
+//              last knot x[:, 1] (the reference passes fill_value=(output[:, 0], output[:, 1]))      (:450-455)
+//   out[t]   = dem[t + shift] (zeros in the last `shift` samples) when shift = y_idx[0] - x_idx[0] > 0 (:458-465)
+// Data-parallel over samples, HBM/latency-bound; not on the hot path (dataset preparation).
+#include "ntm_common.h"
+
+namespace ntm {
+
+#pragma clang fp contract(off)   // slope * dx + y0 must round like numpy does (no FMA)
+
+template <typename T>
+__device__ __forceinline__ int64_t searchsorted_left(const T *a, int64_t n, double v)
+{
+    int64_t lo = 0, hi = n;      // first index with a[idx] >= v
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((double)a[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void demod_yhat_kernel(const int64_t *y_idx, int P, int64_t period, int64_t N, double *y_hat)
+{
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
+    int64_t hi = searchsorted_left(y_idx, (int64_t)P, (double)j);
+    hi = hi < 1 ? 1 : (hi > P - 1 ? P - 1 : hi);
+    const int64_t lo = hi - 1;
+    const double x_lo = (double)y_idx[lo], x_hi = (double)y_idx[hi];
+    const double v_lo = (double)(y_idx[0] + lo * period), v_hi = (double)(y_idx[0] + hi * period);
+    const double slope = (v_hi - v_lo) / (x_hi - x_lo);
+    y_hat[j] = slope * ((double)j - x_lo) + v_lo;
+}
+
+__global__ __launch_bounds__(256) void demod_apply_kernel(const float *x, float *out, int C, int64_t N, int64_t shift,
+                                                          const double *y_hat)
+{
+    const int64_t tp = (int64_t)blockIdx.x * 256 + threadIdx.x;      // output position
+    if (tp >= N) return;
+    const int64_t t = shift > 0 ? tp + shift : tp;                   // position before the roll
+    if (t >= N) {
+        for (int c = 0; c < C; ++c) out[c * N + tp] = 0.0f;
+        return;
+    }
+    const double tv = (double)t;
+    if (tv < y_hat[0] || tv > y_hat[N - 1]) {
+        const int64_t src = tv < y_hat[0] ? 0 : 1;
+        for (int c = 0; c < C; ++c) out[c * N + tp] = x[c * N + src];
+        return;
+    }
+    int64_t hi = searchsorted_left(y_hat, N, tv);
+    hi = hi < 1 ? 1 : (hi > N - 1 ? N - 1 : hi);
+    const int64_t lo = hi - 1;
+    const double x_lo = y_hat[lo], dx = y_hat[hi] - x_lo, dt = tv - x_lo;
+    for (int c = 0; c < C; ++c) {
+        const double v_lo = (double)x[c * N + lo], v_hi = (double)x[c * N + hi];
+        const double slope = (v_hi - v_lo) / dx;
+        out[c * N + tp] = (float)(slope * dt + v_lo);
+    }
+}
+
+hipError_t launch_demodulate(const float *x, float *out, int C, int64_t N, const int64_t *y_idx, int P, int64_t period,
+                             int64_t shift, double *scratch, hipStream_t stream)
+{
+    const unsigned grid = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(demod_yhat_kernel, dim3(grid), dim3(256), 0, stream, y_idx, P, period, N, scratch);
+    hipLaunchKernelGGL(demod_apply_kernel, dim3(grid), dim3(256), 0, stream, x, out, C, N, shift, scratch);
+    return hipGetLastError();
+}
+
+}   // namespace ntm

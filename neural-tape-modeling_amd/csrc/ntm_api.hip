@@ -15,6 +15,8 @@ hipError_t launch_esr_dcpre(const float *y, const float *t, int64_t B, int64_t T
                             hipStream_t stream);
 hipError_t launch_stft_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int n_fft, int hop,
                             int win, float eps, int chunks, double *out, hipStream_t stream);
+hipError_t launch_demodulate(const float *x, float *out, int C, int64_t N, const int64_t *y_idx, int P, int64_t period,
+                             int64_t shift, double *scratch, hipStream_t stream);
 hipError_t launch_tape_hmag(const double *H, double *M, int64_t B, int64_t N, double *state, double Ts, const double *par,
                             hipStream_t stream);
 hipError_t launch_tcn(const float *params, int L, int C, int K, const int *dil, const float *x, float *y, int64_t B,
@@ -160,10 +162,24 @@ int ntm_stft_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t 
     if (chunks < 1 || B * (int64_t)chunks > 0x7fffffff) return fail(NTM_EINVAL, "ntm_stft_sums: bad chunks");
     if (B == 0) return NTM_OK;
     if (T - skip <= n_fft / 2) return fail(NTM_EINVAL, "ntm_stft_sums: reflect padding needs T - skip > n_fft/2");
-    if ((T - skip) / hop + 1 > 0x7fffffff) return fail(NTM_EINVAL, "ntm_stft_sums: too many frames");
+    if (T - skip > 0x7fffffff - 4096) return fail(NTM_EINVAL, "ntm_stft_sums: T - skip must be below 2^31 - 4096");
     if (!y || !t || !out) return fail(NTM_EINVAL, "ntm_stft_sums: null pointer");
     hipError_t e = ntm::launch_stft_sums(y, t, B, T, skip, n_fft, hop, win_length, power_eps, chunks, out, (hipStream_t)stream);
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_stft_sums");
+}
+
+int ntm_demodulate(const float *x, float *out, int C, int64_t N, const int64_t *y_idx, int P, int64_t period, int64_t shift,
+                   double *scratch, void *stream)
+{
+    if (C < 0 || N < 0) return fail(NTM_EINVAL, "ntm_demodulate: negative size");
+    if (P < 2) return fail(NTM_EINVAL, "ntm_demodulate: at least two pulses are needed");
+    if (period <= 0) return fail(NTM_EINVAL, "ntm_demodulate: pulse period must be positive");
+    if (C == 0 || N == 0) return NTM_OK;
+    if (N < 2) return fail(NTM_EINVAL, "ntm_demodulate: N must be at least 2");
+    if (!x || !out || !y_idx || !scratch) return fail(NTM_EINVAL, "ntm_demodulate: null pointer");
+    if (x == out) return fail(NTM_EINVAL, "ntm_demodulate: out must not alias x");
+    hipError_t e = ntm::launch_demodulate(x, out, C, N, y_idx, P, period, shift, scratch, (hipStream_t)stream);
+    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_demodulate");
 }
 
 int ntm_tape_hmag(const double *H, double *M, int64_t B, int64_t N, double *state, double Ts, const double *params5,

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void stft_sums_kernel(StftArgs a)
 
     const int64_t stream = blockIdx.x / a.chunks;
     const int chunk = blockIdx.x % a.chunks;
-    const int64_t L = a.T - a.skip;
+    const int L = (int)(a.T - a.skip);
     const float *ys = a.y + stream * a.T + a.skip;
     const float *ts = a.t + stream * a.T + a.skip;
     const int f_begin = chunk * a.frames_per_chunk;
@@ -79,10 +79,10 @@ __global__ __launch_bounds__(256) void stft_sums_kernel(StftArgs a)
     for (int f = f_begin + wave; f < f_end; f += 4) {
         // ---- windowed frame pair into registers: v[q] = w[n] (y, t)[f hop + n - N/2], reflected at the ends ----
         f2 v[P];
-        const int64_t base = (int64_t)f * a.hop - N / 2 + lane;
+        const int base = f * a.hop - N / 2 + lane;          // (T - skip < 2^31 - n_fft: checked by the API)
 #pragma unroll
         for (int q = 0; q < P; ++q) {
-            int64_t i = base + 64 * q;
+            int i = base + 64 * q;
             i = i < 0 ? -i : i;
             i = i >= L ? 2 * (L - 1) - i : i;
             v[q] = (f2){wreg[q] * ys[i], wreg[q] * ts[i]};

@@ -6,9 +6,16 @@ the '[' ']' glob escaping (:133), one sample rate across the set, files cut into
 consecutive segments of `length` samples starting at `int(sync * fs)` (:243-256), `(input, target, meta)`
 items with the reference's `meta['input_name']` / `['target_name']` strings (:412-419), a segment longer
 than a file raising ValueError (:202-204), channel 0 = audio.
-What is NOT kept (out of scope): DelayAnalyzer (pulse-train analysis), demodulation,
-fractional sub-sampling, shuffling, half/double storage.  Delay trajectories are taken from
-`trajectory_<id>_*.npy` side-cars (seconds, one value per sample) when they exist.
+Delay trajectories come from the `trajectory_<id>_*.npy` side-cars the reference's DelayAnalyzer caches next to
+the audio (code/utilities/utilities.py:269-337: a pickled dict with `delay_trajectory` [seconds, one value per
+sample], `input_peaks`, `output_peaks`; a plain array of seconds is accepted too); from them the feeder keeps the
+analyser's `max_delay` / `min_delay` / `mean_delay` statistics (:191-193, :296-300 -- `max_delay` is what
+code/test-model.py:323-324 turns into INIT_LEN and the model's delay-line length), cuts the pulse indices per
+segment (code/dataset.py:262-279) and, with `demodulate=True`, demodulates the targets on the device
+(`demodulate()` below = DelayAnalyzer.demodulate, :408-465) and drops the mean delay from the segment ends
+(code/dataset.py:395-408).
+What is NOT kept (out of scope): the pulse-train ANALYSIS itself (scipy find_peaks heuristics,
+:466-610 -- side-cars must exist), fractional sub-sampling, shuffling, half/double storage.
 The dataset itself (Zenodo 8026272) is not available here, so this module is checked against synthetic
 files only (tests/test_feeder.py).
 """
@@ -19,6 +26,9 @@ import re
 import numpy as np
 import torch
 from scipy.io import wavfile
+
+from . import _lib
+from ._lib import ptr
 
 
 def read_wav(path):
@@ -41,10 +51,65 @@ def _file_id(path):
     return int(os.path.basename(path).split("_")[1])
 
 
+def load_trajectory(path):
+    """A `trajectory_<id>_*.npy` side-car -> dict(delay_trajectory [s], input_peaks, output_peaks).
+    The reference writes a pickled dict (code/utilities/utilities.py:327-335, read back at :281-282 with
+    allow_pickle=True); a plain float array holding only the trajectory is accepted as well."""
+    try:
+        a = np.load(path)
+    except ValueError:                                   # object array: needs pickle, as in the reference
+        a = np.load(path, allow_pickle=True)
+    if a.dtype == object:
+        d = a.item()
+        return {"delay_trajectory": np.asarray(d["delay_trajectory"], np.float64),
+                "input_peaks": np.asarray(d["input_peaks"]).reshape(-1).astype(np.int64),
+                "output_peaks": np.asarray(d["output_peaks"]).reshape(-1).astype(np.int64)}
+    return {"delay_trajectory": np.asarray(a, np.float64), "input_peaks": None, "output_peaks": None}
+
+
+def segment_peaks(input_peaks, output_peaks, offset, end, length):
+    """Pulse indices of one segment, relative to its start: code/dataset.py:262-279 (including its use of the
+    last pulse INDEX VALUE as a slice bound when the segment runs past the last pulse)."""
+    if input_peaks is None or offset > int(np.max(input_peaks)):
+        return None, None
+    first_idx = np.where(input_peaks >= offset)[0][0]
+    last_idx = np.where(input_peaks <= end)[0][-1] if end <= int(np.max(input_peaks)) else input_peaks[-1]
+    pin = input_peaks[first_idx:last_idx] - offset
+    pout = output_peaks[first_idx:last_idx] - offset
+    return pin, pout[pout <= length]
+
+
+@torch.no_grad()
+def demodulate(output, x_idx_pulse, y_idx_pulse):
+    """DelayAnalyzer.demodulate (code/utilities/utilities.py:408-465) on the device: `output` (C,N) tensor (the
+    reference passes the 2-channel target: audio + pilot pulses), pulse indices as integer arrays.
+    Returns a new (C,N) fp32 tensor.  Needs the HIP library; there is no CPU fallback."""
+    x_idx = np.asarray(x_idx_pulse).reshape(-1).astype(np.int64)
+    y_idx = np.asarray(y_idx_pulse).reshape(-1).astype(np.int64)
+    assert output.dim() == 2, "output should be (channels, samples)"
+    assert len(x_idx) >= 2 and len(y_idx) >= 2, "need at least two pulses"
+    if not output.is_cuda:
+        raise _lib.NtmError("demodulate: tensor must live on the GPU (no CPU fallback)")
+    x = output.to(torch.float32).contiguous()
+    C, N = x.shape
+    period = int(np.mean(np.diff(x_idx)))
+    shift = int(y_idx[0] - x_idx[0])
+    yi = torch.from_numpy(y_idx).to(x.device)
+    out = torch.empty_like(x)
+    scratch = torch.empty(N, device=x.device, dtype=torch.float64)
+    rc = _lib.lib().ntm_demodulate(ptr(x), ptr(out), C, N, ptr(yi), len(y_idx), period, shift, ptr(scratch),
+                                   _lib.current_stream())
+    _lib.check(rc, "ntm_demodulate")
+    return out
+
+
 class SegmentFeeder:
-    def __init__(self, data_dir, subset="train", length=44100, input_only=False, sync=0.0):
+    def __init__(self, data_dir, subset="train", length=44100, input_only=False, sync=0.0, demodulate=False):
         assert os.path.exists(data_dir), "Can't find chosen data_dir"
+        assert not (input_only and demodulate), "Can't demodulate without inputs"       # code/dataset.py:68
         self.data_dir, self.subset, self.length, self.input_only, self.sync = data_dir, subset, length, input_only, sync
+        self.demodulate = demodulate
+        self.mean_delay, self.max_delay, self.min_delay = 0.0, 0.0, 1e6              # DelayAnalyzer, utilities.py:191-193
         search_dir = re.sub(r'([\[\]])', '[\\1]', data_dir)                      # escape [ and ]
         search_string = "**" if subset == "full" else subset.capitalize()
         self.input_files = sorted(glob.glob(os.path.join(search_dir, search_string, "input_*.wav")))
@@ -76,11 +141,18 @@ class SegmentFeeder:
                 t, _ = read_wav(tfile)
                 if x.shape[-1] != t.shape[-1]:
                     raise RuntimeError("Found potentially corrupt file!")
-            d = np.load(traj[_file_id(ifile)]).astype(np.float32) if _file_id(ifile) in traj else None
+            d = load_trajectory(traj[_file_id(ifile)]) if _file_id(ifile) in traj else None
+            if d is not None:                                                          # utilities.py:296-300
+                self.mean_delay += float(np.mean(d["delay_trajectory"]))
+                self.max_delay = max(self.max_delay, float(np.max(d["delay_trajectory"])))
+                self.min_delay = min(self.min_delay, float(np.min(d["delay_trajectory"])))
             self._audio.append((x, t, d))
             start = int(self.sync * self.fs)
             for n_chunk in range((num_frames - start) // self.length):
                 self.examples.append({"idx": idx, "offset": n_chunk * self.length + start})
+        n_traj = sum(1 for a in self._audio if a[2] is not None)
+        self.mean_delay = self.mean_delay / n_traj if n_traj else 0.0               # utilities.py:341
+        assert not (demodulate and n_traj != len(self._audio)), "Can't demodulate without trajectory side-cars!"
         self.minutes = self.length * len(self.examples) / self.fs / 60
 
     def __len__(self):
@@ -96,9 +168,20 @@ class SegmentFeeder:
         if self.input_only:
             return inp, meta
         meta["target_name"] = name(self.target_files[ex["idx"]])
+        tgt = torch.from_numpy(t[:, o:e])
         if d is not None:
-            meta["delay_trajectory"] = torch.from_numpy(d[o:e])
-        return inp, torch.from_numpy(t[:, o:e]), meta
+            T_delay = torch.from_numpy(d["delay_trajectory"][o:e].astype(np.float32))
+            pin, pout = segment_peaks(d["input_peaks"], d["output_peaks"], o, e, self.length)
+            if self.demodulate:                                                        # code/dataset.py:395-408
+                assert pin is not None, "Can't demodulate without pulse indices!"
+                tgt = demodulate(tgt.cuda(), pin, pout).cpu()
+                cut = int(self.mean_delay * self.fs)
+                inp, tgt, T_delay = inp[:, :-cut], tgt[:, :-cut], T_delay[:-cut]
+                pin = pin[pin <= inp.shape[-1]]
+                pout = pin                                                             # as upstream ("assume everything works")
+            meta["delay_trajectory"] = T_delay
+            meta["input_peaks"], meta["output_peaks"] = pin, pout
+        return inp, tgt, meta
 
     def batches(self, batch_size, device="cuda", rank=0, world=1):
         """Yield (input (B,1,L), target (B,1,L) | None, d_traj_seconds (B,1,L) | None, metas) on `device`
@@ -111,7 +194,7 @@ class SegmentFeeder:
             stack = lambda k: torch.stack([it[k][:1] for it in items])                # noqa: E731  audio = channel 0
             xin = stack(0)
             tgt = None if self.input_only else stack(1)
-            metas = [it[-1] for it in items]
+            metas = [{k: v for k, v in it[-1].items() if not k.endswith("_peaks")} for it in items]
             dt = None
             if all("delay_trajectory" in m for m in metas):
                 dt = torch.stack([m["delay_trajectory"] for m in metas]).unsqueeze(1)

@@ -217,6 +217,33 @@ def mrstft_per_segment(y, t, skip=0, resolutions=MRSTFT_RESOLUTIONS):
     return total / len(resolutions)
 
 
+def _lin_interp(xk, yk, xn):
+    """scipy.interpolate.interp1d(kind='linear')._call_linear restated: knots xk (increasing), values yk [..., K]."""
+    idx = np.clip(np.searchsorted(xk, xn), 1, len(xk) - 1)
+    lo, hi = idx - 1, idx
+    slope = (yk[..., hi] - yk[..., lo]) / (xk[hi] - xk[lo])
+    return slope * (xn - xk[lo]) + yk[..., lo]
+
+
+def demodulate(output, x_idx_pulse, y_idx_pulse):
+    """DelayAnalyzer.demodulate, code/utilities/utilities.py:408-465 (fp64): undo the time-varying delay of a
+    (C, N) recording from its input / output pulse indices.  Pinned by golden g11 (the reference's own output)."""
+    output = np.asarray(output, np.float64)
+    x_idx, y_idx = np.asarray(x_idx_pulse).reshape(-1), np.asarray(y_idx_pulse).reshape(-1)
+    period = int(np.mean(np.diff(x_idx)))                                   # :436
+    y_hat_idx = y_idx[0] + np.arange(len(y_idx)) * period                   # :437-438  (Eq. 57)
+    t = np.arange(output.shape[-1])
+    y_hat = _lin_interp(y_idx.astype(np.float64), y_hat_idx.astype(np.float64), t.astype(np.float64))   # :441-447, extrapolating
+    dem = _lin_interp(y_hat, output, t.astype(np.float64))                  # :450-455
+    dem[:, t < y_hat[0]] = output[:, :1]                                    # fill_value = (output[:, 0], output[:, 1]):
+    dem[:, t > y_hat[-1]] = output[:, 1:2]                                  # the "above" value is SAMPLE 1, as upstream
+    shift = int(y_idx[0] - x_idx[0])
+    if shift > 0:                                                           # :458-465
+        dem = np.roll(dem, -shift, axis=1)
+        dem[:, -shift:] = 0.0
+    return dem
+
+
 TAPE_PARAMS = (1.6e6, 1.1e3, 1.6e-3, 4.0e2, 1.7e-1)      # Ms, A, alpha, K, c  (code/tape.py:251-256)
 
 

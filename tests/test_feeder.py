@@ -59,3 +59,47 @@ def test_id_mismatch_and_wav_scaling(tmp_path):
     os.rename(os.path.join(root, "Test", "target_7_.wav"), os.path.join(root, "Test", "target_8_.wav"))
     with pytest.raises(RuntimeError, match="non-matching file ids"):
         SegmentFeeder(root, subset="test", length=1000)
+
+
+def test_reference_sidecar_format_stats_and_segment_peaks(tmp_path):
+    """The reference's DelayAnalyzer caches a PICKLED DICT per file (code/utilities/utilities.py:327-335); the feeder
+    reads it, keeps max/min/mean delay like the analyser (:191-193, :296-300, :341) and cuts the pulse indices per
+    segment as code/dataset.py:262-279 does."""
+    from ntm_amd.feeder import load_trajectory, segment_peaks
+    root, _ = make_dataset(str(tmp_path), n_files=2, frames=(10000, 9000), stereo=True)
+    d = os.path.join(root, "Test")
+    pk_in = np.arange(50, 9000, 441)
+    for i, (n, d0) in enumerate([(10000, 0.020), (9000, 0.030)]):
+        traj = d0 + 0.002 * np.sin(np.arange(n) / 500.0)
+        np.save(os.path.join(d, f"trajectory_{i + 7}_.npy"),
+                {"input_peaks": pk_in, "input_meta": {"reconstruction_percentage": 0.0, "wiggle_percentage": 0.0},
+                 "output_peaks": pk_in + 900 + i, "output_meta": {"reconstruction_percentage": 0.0, "wiggle_percentage": 0.0},
+                 "delay_trajectory": traj})
+    t0 = load_trajectory(os.path.join(d, "trajectory_7_.npy"))
+    assert t0["delay_trajectory"].shape == (10000,) and np.array_equal(t0["output_peaks"], pk_in + 900)
+    f = SegmentFeeder(root, subset="test", length=4000)
+    trajs = [0.020 + 0.002 * np.sin(np.arange(10000) / 500.0), 0.030 + 0.002 * np.sin(np.arange(9000) / 500.0)]
+    assert abs(f.max_delay - max(t.max() for t in trajs)) < 1e-12 and abs(f.min_delay - min(t.min() for t in trajs)) < 1e-12
+    assert abs(f.mean_delay - np.mean([t.mean() for t in trajs])) < 1e-12
+    x, t, meta = f[1]                                                  # file 0, offset 4000
+    assert np.allclose(meta["delay_trajectory"].numpy(), trajs[0][4000:8000], atol=1e-7)
+    first = np.where(pk_in >= 4000)[0][0]; last = np.where(pk_in <= 8000)[0][-1]
+    assert np.array_equal(meta["input_peaks"], pk_in[first:last] - 4000)
+    want_out = (pk_in + 900)[first:last] - 4000
+    assert np.array_equal(meta["output_peaks"], want_out[want_out <= 4000])
+    # segment past the last pulse: the reference then slices with the last pulse's VALUE (code/dataset.py:269-270)
+    pi, po = segment_peaks(pk_in, pk_in + 900, 8000, 12000, 4000)
+    assert np.array_equal(pi, pk_in[np.where(pk_in >= 8000)[0][0]:pk_in[-1]] - 8000)
+    assert segment_peaks(pk_in, pk_in + 900, 9500, 13500, 4000) == (None, None)      # offset beyond the last pulse
+    # peaks stay out of the collated batch metadata
+    b = next(f.batches(2, device="cpu"))
+    assert b[2].shape == (2, 1, 4000) and all("input_peaks" not in m for m in b[3])
+
+
+def test_g11_demodulate_oracle_is_the_reference():
+    """N3: the oracle's demodulate against the reference's own DelayAnalyzer.demodulate output (bit-exact)."""
+    import oracle
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g11_demodulate.npz"))
+    for i in range(int(g["n"])):
+        dem = oracle.demodulate(g[f"out{i}"], g[f"x{i}"], g[f"y{i}"])
+        assert np.array_equal(dem, g[f"dem{i}"]), i

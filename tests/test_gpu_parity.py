@@ -467,6 +467,8 @@ def test_cli_loss_over_synthetic_dataset(ntm, tmp_path):
     sd = oracle.esr_dcpre_sums(yo, Tg, 1024); n = L - 1024
     want_dc = float(np.mean((sd[:, 0] / n) / (sd[:, 1] / n + 1e-5)))
     assert len(f) == 6 and abs(got["ESR"] - want) < 1e-3 * want and abs(got["DCPreESR"] - want_dc) < 1e-3 * want_dc
+    want_st = float(np.mean(oracle.mrstft_per_segment(yo, Tg, 1024)))
+    assert abs(got["MultiSTFT"] - want_st) < 1e-3 * want_st
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -568,3 +570,46 @@ def test_stft_sums_errors(ntm):
         ntm.stft_sums(y, y, 4096 - 512, 1024, 120, 600)   # T - skip <= n_fft/2: reflect padding impossible
     with pytest.raises(ntm.NtmError):
         ntm.stft_sums(y, y, 0, 1024, 120, 1025)           # window longer than the frame
+
+
+def test_g11_demodulate(ntm):
+    """N3: the device demodulation against the reference's own DelayAnalyzer.demodulate output (fp64 there,
+    rounded to fp32 here): positive, zero and negative input/output offsets, truncated pulse trains."""
+    from ntm_amd.feeder import demodulate
+    g = load("g11_demodulate.npz")
+    for i in range(int(g["n"])):
+        dem = demodulate(dev(g[f"out{i}"]), g[f"x{i}"], g[f"y{i}"]).cpu().numpy()
+        want = g[f"dem{i}"]
+        assert dem.shape == want.shape
+        assert np.array_equal(dem, want.astype(np.float32)), (i, np.abs(dem - want).max())
+    with pytest.raises(ntm.NtmError):
+        demodulate(dev(g["out0"]), np.array([5, 5]), g["y0"])            # period 0
+    with pytest.raises(AssertionError):
+        demodulate(dev(g["out0"]), g["x0"], g["y0"][:1])                 # a single pulse
+
+
+def test_feeder_demodulated_targets(ntm, tmp_path):
+    """Feeder with demodulate=True (code/dataset.py:395-408): target demodulated on the device, mean delay cut."""
+    from scipy.io import wavfile
+    from ntm_amd.feeder import SegmentFeeder, segment_peaks
+    g = load("g11_demodulate.npz")
+    d = tmp_path / "Set" / "Test"
+    d.mkdir(parents=True)
+    out, x_idx, y_idx = g["out0"], g["x0"], g["y0"]
+    N = out.shape[1]
+    wavfile.write(str(d / "input_1_.wav"), 44100, np.stack([out[0], np.zeros(N, np.float32)], 1))
+    wavfile.write(str(d / "target_1_.wav"), 44100, out.T.copy())
+    traj = np.full(N, 1200 / 44100.0)
+    np.save(str(d / "trajectory_1_.npy"), {"input_peaks": x_idx, "input_meta": {}, "output_peaks": y_idx, "output_meta": {},
+                                           "delay_trajectory": traj})
+    f = SegmentFeeder(str(tmp_path / "Set"), subset="test", length=14000, demodulate=True)
+    assert len(f) == 2
+    cut = int(f.mean_delay * 44100)
+    for k in range(2):
+        x, t, meta = f[k]
+        o = 14000 * k
+        pi, po = segment_peaks(x_idx, y_idx, o, o + 14000, 14000)
+        want = oracle.demodulate(out[:, o:o + 14000], pi, po)[:, :-cut]
+        assert t.shape == (2, 14000 - cut) and x.shape == (2, 14000 - cut)
+        assert np.array_equal(t.numpy(), want.astype(np.float32))
+        assert len(meta["delay_trajectory"]) == 14000 - cut and np.array_equal(meta["output_peaks"], meta["input_peaks"])

@@ -5,8 +5,9 @@ on the MI355X engine: same UPPER_CASE flags where they apply, batched over segme
     python tools/test_model.py --DATASET_DIR <dir with Test/input_*.wav, target_*.wav> \
         --WEIGHTS "GRU-HS[64]-L[DCPreESR]-DS[...]_BEST" --SEGMENT_LENGTH 441000 --BATCH_SIZE 64 --COMPUTE_LOSS
 
-Differences: plotting / WAV export / noise / demodulation are out of scope; DiffDelGRU needs
-`trajectory_<id>_*.npy` side-cars (seconds) and `--MAX_DELAY` (seconds) because DelayAnalyzer is not built;
+Differences: plotting / WAV export / noise are out of scope; DiffDelGRU, `--DEMODULATE` and the dataset-derived
+INIT_LEN need the `trajectory_<id>_*.npy` side-cars DelayAnalyzer caches (its pulse analysis is not built; without
+side-cars give `--MAX_DELAY` in seconds);
 `--WEIGHTS` names one of the exported checkpoints (ntm_amd.weights.available()) or a directory with best.pth.
 """
 import argparse
@@ -32,12 +33,15 @@ def main(argv=None):
     p.add_argument('--BATCH_SIZE', type=int, default=64)
     p.add_argument('--MAX_DELAY', type=float, default=0.0, help="seconds (DelayAnalyzer.max_delay of the dataset)")
     p.add_argument('--COMPUTE_LOSS', action='store_true', default=False)
+    p.add_argument('--DEMODULATE', action='store_true', default=False)
     p.add_argument('--KERNEL', type=str, default="auto")
     a = p.parse_args(argv)
 
     rank, world, local = D.init_from_env()
     torch.cuda.set_device(local)
-    feeder = SegmentFeeder(a.DATASET_DIR, subset=a.SUBSET, length=a.SEGMENT_LENGTH, sync=a.SYNC)
+    feeder = SegmentFeeder(a.DATASET_DIR, subset=a.SUBSET, length=a.SEGMENT_LENGTH, sync=a.SYNC, demodulate=a.DEMODULATE)
+    if a.MAX_DELAY <= 0 and feeder.max_delay > 0:          # dataset.delay_analyzer.max_delay (code/test-model.py:323-324)
+        a.MAX_DELAY = feeder.max_delay
     sd = None
     if os.path.isdir(a.WEIGHTS):
         sd = torch.load(os.path.join(a.WEIGHTS, "best.pth"), map_location="cpu")
@@ -49,7 +53,8 @@ def main(argv=None):
     if not a.COMPUTE_LOSS:
         print(f"{len(feeder)} segments of {feeder.length} samples @ {feeder.fs} Hz; nothing to do without --COMPUTE_LOSS")
         return {}
-    per = {"ESR": [], "DCPreESR": []}
+    per = {"ESR": [], "DCPreESR": [], "MultiSTFT": []}
+    mrstft = ntm_amd.MRSTFTLoss()
     for xin, tgt, dt, _ in feeder.batches(a.BATCH_SIZE, "cuda", rank, world):
         if is_dd:
             assert dt is not None, "DiffDelGRU needs trajectory_<id>_*.npy side-cars"
@@ -60,6 +65,10 @@ def main(argv=None):
         for key, fn in (("ESR", esr_sums), ("DCPreESR", esr_dcpre_sums)):
             s = fn(out, tgt, skip=init_len)
             per[key].append((s[:, 0] / n) / (s[:, 1] / n + ESR_EPS))
+        if n > 1024:                                          # the largest STFT frame needs > 1024 samples
+            per["MultiSTFT"].append(mrstft.per_segment(out, tgt, skip=init_len))
+    if not per["MultiSTFT"]:
+        del per["MultiSTFT"]
     res = {k: D.reduce_loss_sums(torch.cat(v) if v else torch.zeros(0, device="cuda", dtype=torch.float64))
            for k, v in per.items()}
     if rank == 0:
