@@ -163,7 +163,7 @@ def main():
 
     import ntm_amd
     from ntm_amd import distributed as D, weights
-    from ntm_amd.model import esr_sums, ESR_EPS
+    from ntm_amd.model import esr_sums, esr_dcpre_sums, MRSTFTLoss, ESR_EPS
 
     if a.workload != "gru":
         return side_workload(a)
@@ -254,6 +254,19 @@ def main():
             extra["f16x3"]["stream0_vs_reference_max_abs"] = float(
                 np.abs(gold["y"][0, 0] - y2[0, 0].cpu().numpy()).max())
         model.kernel_variant = a.variant
+        # the loss dict that follows the path in code/test-model.py:250-254 (never part of `value` beyond the ESR
+        # sums the timed step already contains): ESR, DCPreESR and MultiSTFT over the whole batch, f16x3 output
+        # against the exact-fp32 output
+        lm = {}
+        for name, fn in (("ESR", lambda: esr_sums(y2, target, skip=INIT_LEN)),
+                         ("DCPreESR", lambda: esr_dcpre_sums(y2, target, skip=INIT_LEN)),
+                         ("MultiSTFT", lambda: MRSTFTLoss().per_segment(y2, target, skip=INIT_LEN))):
+            for _ in range(2):
+                ev0.record(); r = fn(); ev1.record(); torch.cuda.synchronize()
+            lm[name + "_ms"] = ev0.elapsed_time(ev1)
+        lm["MultiSTFT_f16x3_vs_exact_mean"] = float(r.mean())
+        extra["loss_pass"] = lm
+        del y2
     if rank != 0:
         return
     total_samples = float(B) * T * world * a.steps
