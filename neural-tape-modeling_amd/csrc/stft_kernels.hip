@@ -9,13 +9,14 @@
 //
 // Mapping: one 64-lane wave transforms one frame PAIR: z = w*(y + i t) goes through ONE complex n_fft-point
 // FFT, and the two real spectra are separated afterwards (Y[k] = (Z[k] + conj Z[N-k])/2,
-// T[k] = (Z[k] - conj Z[N-k])/(2i)).  The FFT is a Stockham autosort radix-4 (plus one radix-2 pass when
-// log2 n_fft is odd); each lane holds n_fft/64 points in registers, passes exchange through the wave's own
+// T[k] = (Z[k] - conj Z[N-k])/(2i)).  The FFT is a Stockham autosort FFT in three passes of radix 16/8/4
+// (256 = 4.4.4.4, 512 = 8.8.8, 1024 = 16.4.16, 2048 = 16.8.16): each lane holds n_fft/64 points in registers
+// and runs whole radix-R butterflies on them; passes exchange through the wave's own (padded, conflict-free)
 // LDS buffer, so no workgroup barrier is needed inside the frame loop (LDS operations of one wave are
-// processed in issue order).  The window values and their positions are per-lane constants kept in registers;
-// twiddles come from an LDS table computed once per workgroup with sincospi.  A workgroup = 4 waves works on
-// one (stream, frame chunk); sums are accumulated in fp64 per lane and written per (stream, chunk, wave) --
-// the host adds them in a fixed order (deterministic, no atomics).
+// processed in issue order).  Window values and pass twiddles are per-lane, frame-invariant constants kept
+// in registers (computed once with sincospi).  A workgroup = 4 waves works on one (stream, frame chunk);
+// sums are accumulated in fp64 per lane and written per (stream, chunk, wave) -- the host adds them in a
+// fixed order (deterministic, no atomics).
 //
 // Bound: VALU (about 5 n log2 n flop per frame pair); the signals are read once from HBM per resolution
 // (frames overlap 5x in L1/L2), 8 B/sample algorithmic.
@@ -34,6 +35,7 @@ struct StftArgs {
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f2 cmul(f2 a, f2 b) { return (f2){a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ f2 mul_mi(f2 a) { return (f2){a.y, -a.x}; }             // a * (-i)
 
 __device__ __forceinline__ void wave_lds_fence()
 {
@@ -42,21 +44,140 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int LOG2N>
-__global__ __launch_bounds__(256) void stft_sums_kernel(StftArgs a)
+// ---- in-register DFTs (forward, e^{-2 pi i nk/R}), natural order in and out -------------------------------
+__device__ __forceinline__ void dft2(f2 &a, f2 &b) { const f2 t = a; a = t + b; b = t - b; }
+
+__device__ __forceinline__ void dft4(f2 &x0, f2 &x1, f2 &x2, f2 &x3)
 {
-    constexpr int N = 1 << LOG2N, P = N / 64, NB4 = P / 4, NPASS4 = LOG2N / 2;
-    constexpr bool ODD = (LOG2N & 1) != 0;
+    const f2 s02 = x0 + x2, d02 = x0 - x2, s13 = x1 + x3, jd = mul_mi(x1 - x3);
+    x0 = s02 + s13; x1 = d02 + jd; x2 = s02 - s13; x3 = d02 - jd;
+}
+
+constexpr float C8 = 0.70710678118654752f;                       // cos(pi/4)
+constexpr float C16 = 0.92387953251128674f, S16 = 0.38268343236508977f;   // cos, sin(pi/8)
+
+template <int R> __device__ __forceinline__ void dft(f2 (&x)[R]);
+
+template <> __device__ __forceinline__ void dft<2>(f2 (&x)[2]) { dft2(x[0], x[1]); }
+template <> __device__ __forceinline__ void dft<4>(f2 (&x)[4]) { dft4(x[0], x[1], x[2], x[3]); }
+
+// R = 8 = 4 x 2:  n = 2 n1 + n2,  k = k1 + 4 k2
+template <> __device__ __forceinline__ void dft<8>(f2 (&x)[8])
+{
+    dft4(x[0], x[2], x[4], x[6]);                                 // n2 = 0: a[0][k1] in x[2 k1]
+    dft4(x[1], x[3], x[5], x[7]);                                 // n2 = 1: a[1][k1] in x[2 k1 + 1]
+    x[3] = (f2){C8 * (x[3].x + x[3].y), C8 * (x[3].y - x[3].x)};  // * W8^1 = (c, -c)
+    x[5] = mul_mi(x[5]);                                          // * W8^2
+    x[7] = (f2){C8 * (x[7].y - x[7].x), -C8 * (x[7].x + x[7].y)}; // * W8^3 = (-c, -c)
+    f2 y[8];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) { y[k1] = x[2 * k1] + x[2 * k1 + 1]; y[k1 + 4] = x[2 * k1] - x[2 * k1 + 1]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = y[i];
+}
+
+// R = 16 = 4 x 4:  n = 4 n1 + n2,  k = k1 + 4 k2
+template <> __device__ __forceinline__ void dft<16>(f2 (&x)[16])
+{
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) dft4(x[n2], x[4 + n2], x[8 + n2], x[12 + n2]);    // a[n2][k1] in x[4 k1 + n2]
+    // twiddles W16^(n2 k1)
+    const f2 w1 = {C16, -S16}, w2 = {C8, -C8}, w3 = {S16, -C16}, w6 = {-C8, -C8}, w9 = {-C16, S16};
+    x[4 * 1 + 1] = cmul(x[4 * 1 + 1], w1); x[4 * 1 + 2] = cmul(x[4 * 1 + 2], w2); x[4 * 1 + 3] = cmul(x[4 * 1 + 3], w3);
+    x[4 * 2 + 1] = cmul(x[4 * 2 + 1], w2); x[4 * 2 + 2] = mul_mi(x[4 * 2 + 2]);   x[4 * 2 + 3] = cmul(x[4 * 2 + 3], w6);
+    x[4 * 3 + 1] = cmul(x[4 * 3 + 1], w3); x[4 * 3 + 2] = cmul(x[4 * 3 + 2], w6); x[4 * 3 + 3] = cmul(x[4 * 3 + 3], w9);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) dft4(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);   // X[k1 + 4 k2] in x[4 k1 + k2]
+    f2 y[16];
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1)
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) y[k1 + 4 * k2] = x[4 * k1 + k2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = y[i];
+}
+
+// exchange-buffer index: one float2 of padding per 16 keeps the strided Stockham stores conflict-free
+__device__ __forceinline__ constexpr int padi(int i) { return i + (i >> 4); }
+
+// Per-lane twiddles of one Stockham pass, radix R with sub-transform size Ns: butterfly b of this lane is
+// j = lane + 64 b, k = j mod Ns, and input t is multiplied by exp(-2 pi i t k / (Ns R)).  Frame-invariant.
+template <int N, int R, int Ns> struct PassTw {
+    static constexpr int NB = N / R / 64;
+    static constexpr int NBW = Ns <= 64 ? 1 : NB;      // Ns <= 64: k = lane mod Ns is the same for every butterfly of the lane
+    f2 w[Ns > 1 ? NBW * (R - 1) : 1];
+    __device__ __forceinline__ void init(int lane)
+    {
+        if constexpr (Ns > 1) {
+#pragma unroll
+            for (int b = 0; b < NBW; ++b)
+#pragma unroll
+                for (int t = 1; t < R; ++t) {
+                    const int k = (lane + 64 * b) & (Ns - 1);
+                    float sn, cs;
+                    sincospif(-2.0f * (float)(t * k) / (float)(Ns * R), &sn, &cs);
+                    w[b * (R - 1) + t - 1] = (f2){cs, sn};
+                }
+        }
+    }
+    __device__ __forceinline__ f2 get(int b, int t) const { return w[(NBW == 1 ? 0 : b) * (R - 1) + t - 1]; }
+};
+
+// One Stockham pass over the wave's N points: v[q] holds point lane + 64 q.
+template <int N, int R, int Ns, bool FIRST>
+__device__ __forceinline__ void stockham_pass(f2 (&v)[N / 64], f2 *buf, const PassTw<N, R, Ns> &tw, int lane)
+{
+    constexpr int P = N / 64, NB = N / R / 64;
+    if constexpr (!FIRST) {
+        wave_lds_fence();
+#pragma unroll
+        for (int q = 0; q < P; ++q) v[q] = buf[padi(lane + 64 * q)];
+        wave_lds_fence();
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int j = lane + 64 * b;
+        const int k = j & (Ns - 1);
+        f2 x[R];
+#pragma unroll
+        for (int t = 0; t < R; ++t) x[t] = v[b + t * NB];
+        if constexpr (Ns > 1) {
+#pragma unroll
+            for (int t = 1; t < R; ++t) x[t] = cmul(x[t], tw.get(b, t));
+        }
+        dft<R>(x);
+        const int o = (j - k) * R + k;
+#pragma unroll
+        for (int m = 0; m < R; ++m) buf[padi(o + m * Ns)] = x[m];
+    }
+}
+
+// radix plans: 256 = 4.4.4.4, 512 = 8.8.8, 1024 = 16.4.16, 2048 = 16.8.16 (the small radix in the middle pass,
+// where every butterfly of a lane shares its twiddles: fewer twiddle registers)
+template <int LOG2N> struct Plan;
+template <> struct Plan<8> { static constexpr int R0 = 4, R1 = 4, R2 = 4, R3 = 4; };
+template <> struct Plan<9> { static constexpr int R0 = 8, R1 = 8, R2 = 8, R3 = 1; };
+template <> struct Plan<10> { static constexpr int R0 = 16, R1 = 4, R2 = 16, R3 = 1; };
+template <> struct Plan<11> { static constexpr int R0 = 16, R1 = 8, R2 = 16, R3 = 1; };
+
+template <int LOG2N>
+__global__ __launch_bounds__(256, (LOG2N <= 10 ? 2 : 1)) void stft_sums_kernel(StftArgs a)
+{
+    constexpr int N = 1 << LOG2N, P = N / 64, NPAD = N + N / 16;
+    using PL = Plan<LOG2N>;
+    constexpr int R0 = PL::R0, R1 = PL::R1, R2 = PL::R2, R3 = PL::R3;
+    static_assert(R0 * R1 * R2 * R3 == N, "radix plan");
     extern __shared__ f2 stft_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    f2 *tw = stft_smem;                       // [N]   exp(-2 pi i m / N)
-    f2 *buf = stft_smem + N + wave * N;       // [N]   this wave's exchange buffer
+    f2 *buf = stft_smem + wave * NPAD;        // this wave's exchange buffer
 
-    for (int m = tid; m < N; m += 256) {
-        float s, c;
-        sincospif(-2.0f * (float)m / (float)N, &s, &c);
-        tw[m] = (f2){c, s};
-    }
+    PassTw<N, R1, R0> tw1;
+    PassTw<N, R2, R0 * R1> tw2;
+    PassTw<N, (R3 > 1 ? R3 : 2), R0 * R1 * R2 / (R3 > 1 ? 1 : 2)> tw3;      // (unused when R3 == 1)
+    tw1.init(lane);
+    tw2.init(lane);
+    if constexpr (R3 > 1) tw3.init(lane);
+
     // window value of this lane's points n = lane + 64 q  (periodic Hann of `win` samples, centred in n_fft)
     const int left = (N - a.win) / 2;
     float wreg[P];
@@ -65,7 +186,6 @@ __global__ __launch_bounds__(256) void stft_sums_kernel(StftArgs a)
         const int n = lane + 64 * q - left;
         wreg[q] = (n >= 0 && n < a.win) ? 0.5f - 0.5f * cospif(2.0f * (float)n / (float)a.win) : 0.0f;
     }
-    __syncthreads();
 
     const int64_t stream = blockIdx.x / a.chunks;
     const int chunk = blockIdx.x % a.chunks;
@@ -76,64 +196,50 @@ __global__ __launch_bounds__(256) void stft_sums_kernel(StftArgs a)
     const int f_end = min(f_begin + a.frames_per_chunk, a.n_frames);
 
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    // raw samples of the frame pair, fetched one frame ahead: ry/rt[q] = (y, t)[f hop + lane + 64 q - N/2],
+    // reflected at the ends (torch.stft center=True, pad_mode="reflect")
+    float ry[P], rt[P];
+    auto fetch = [&](int f) {
+        const int start = f * a.hop - N / 2;                // (T - skip < 2^31 - n_fft: checked by the API)
+        if (start >= 0 && start + N <= L) {                 // interior frame (wave-uniform): no index math per load
+            const float *py = ys + start + lane, *pt = ts + start + lane;
+#pragma unroll
+            for (int q = 0; q < P; ++q) { ry[q] = py[64 * q]; rt[q] = pt[64 * q]; }
+        } else {
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                int i = start + lane + 64 * q;
+                i = i < 0 ? -i : i;
+                i = i >= L ? 2 * (L - 1) - i : i;
+                ry[q] = ys[i]; rt[q] = ts[i];
+            }
+        }
+    };
+    if (f_begin + wave < f_end) fetch(f_begin + wave);
     for (int f = f_begin + wave; f < f_end; f += 4) {
-        // ---- windowed frame pair into registers: v[q] = w[n] (y, t)[f hop + n - N/2], reflected at the ends ----
         f2 v[P];
-        const int base = f * a.hop - N / 2 + lane;          // (T - skip < 2^31 - n_fft: checked by the API)
 #pragma unroll
-        for (int q = 0; q < P; ++q) {
-            int i = base + 64 * q;
-            i = i < 0 ? -i : i;
-            i = i >= L ? 2 * (L - 1) - i : i;
-            v[q] = (f2){wreg[q] * ys[i], wreg[q] * ts[i]};
+        for (int q = 0; q < P; ++q) v[q] = (f2){wreg[q] * ry[q], wreg[q] * rt[q]};
+        if constexpr (LOG2N > 10) {
+            if (f + 4 < f_end) fetch(f + 4);                    // in flight during this frame's FFT
         }
-        // ---- radix-4 passes: butterfly b of this lane is j = lane + 64 b, inputs x[j + t N/4] = v[b + t NB4] ----
-#pragma unroll
-        for (int p = 0; p < NPASS4; ++p) {
-            const int Ns = 1 << (2 * p);
-            if (p > 0) {
-                wave_lds_fence();
-#pragma unroll
-                for (int q = 0; q < P; ++q) v[q] = buf[lane + 64 * q];
-                wave_lds_fence();
-            }
-#pragma unroll
-            for (int b = 0; b < NB4; ++b) {
-                const int j = lane + 64 * b;
-                const int k = j & (Ns - 1);
-                f2 x0 = v[b], x1 = v[b + NB4], x2 = v[b + 2 * NB4], x3 = v[b + 3 * NB4];
-                if (p > 0) {
-                    const f2 w1 = tw[k * (N / (4 * Ns))];
-                    const f2 w2 = cmul(w1, w1), w3 = cmul(w1, w2);
-                    x1 = cmul(x1, w1); x2 = cmul(x2, w2); x3 = cmul(x3, w3);
-                }
-                const f2 s02 = x0 + x2, d02 = x0 - x2, s13 = x1 + x3, d13 = x1 - x3;
-                const f2 jd = (f2){d13.y, -d13.x};              // -i (x1 - x3)
-                const int o = ((j - k) << 2) + k;
-                buf[o] = s02 + s13;
-                buf[o + Ns] = d02 + jd;
-                buf[o + 2 * Ns] = s02 - s13;
-                buf[o + 3 * Ns] = d02 - jd;
-            }
+        // ---- Stockham autosort FFT, the wave's own LDS buffer between passes ----
+        {
+            PassTw<N, R0, 1> tw0;
+            stockham_pass<N, R0, 1, true>(v, buf, tw0, lane);
         }
-        if constexpr (ODD) {                                    // last pass radix 2: Ns = N/2, outputs in place
-            wave_lds_fence();
-#pragma unroll
-            for (int q = 0; q < P; ++q) v[q] = buf[lane + 64 * q];
-            wave_lds_fence();
-#pragma unroll
-            for (int b = 0; b < P / 2; ++b) {
-                const int j = lane + 64 * b;
-                const f2 x0 = v[b], x1 = cmul(v[b + P / 2], tw[j]);
-                buf[j] = x0 + x1;
-                buf[j + N / 2] = x0 - x1;
-            }
+        stockham_pass<N, R1, R0, false>(v, buf, tw1, lane);
+        if constexpr (LOG2N <= 10) {
+            // n_fft <= 1024 runs two waves per SIMD (256 VGPRs): fetch late, when the big butterflies are done
+            if (f + 4 < f_end) fetch(f + 4);
         }
+        stockham_pass<N, R2, R0 * R1, false>(v, buf, tw2, lane);
+        if constexpr (R3 > 1) stockham_pass<N, R3, R0 * R1 * R2, false>(v, buf, tw3, lane);
         wave_lds_fence();
         // ---- separate the two real spectra, magnitudes, distance terms for bins k = 0 .. N/2 ----
         float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
         auto bin = [&](int k) {
-            const f2 zk = buf[k], zn = buf[(N - k) & (N - 1)];
+            const f2 zk = buf[padi(k)], zn = buf[padi((N - k) & (N - 1))];
             const float yr = 0.5f * (zk.x + zn.x), yi = 0.5f * (zk.y - zn.y);
             const float tr = 0.5f * (zk.y + zn.y), ti = 0.5f * (zn.x - zk.x);
             const float py = fmaxf(yr * yr + yi * yi, a.eps), pt = fmaxf(tr * tr + ti * ti, a.eps);
@@ -165,7 +271,7 @@ template <int LOG2N>
 static hipError_t launch_one(const StftArgs &a, hipStream_t stream)
 {
     constexpr int N = 1 << LOG2N;
-    const size_t smem = (size_t)5 * N * sizeof(f2);
+    const size_t smem = (size_t)4 * (N + N / 16) * sizeof(f2);
     auto k = stft_sums_kernel<LOG2N>;
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
