@@ -7,25 +7,69 @@
 
 namespace ntm {
 
-struct JaParams { double Ms, A, alpha, K, c; };
+struct JaParams { double Ms, A, alpha, K, c, rA; };   // rA = 1/A
+
+// The recurrence is one wave's dependent fp64 chain (a GPU has far more SIMDs than 4096 streams need waves), so
+// what counts is the DEPTH of the per-sample computation, not its instruction count.  The two helpers below
+// replace ocml's tanh (165 instructions, mostly serial) and the IEEE division (12).
+
+// 1/x for x != 0 (finite, normal): v_rcp_f64 seed r0 (~2^-23), e = 1 - x r0, result r0 (1 + e)(1 + e^2): error
+// e^4, within 1 ulp; dependent depth 4.  Only used where the denominator cannot vanish.
+__device__ __forceinline__ double rcp_nr(double x)
+{
+    const double r0 = __builtin_amdgcn_rcp(x);
+    const double e = fma(-x, r0, 1.0);
+    const double r1 = fma(e, r0, r0), e2 = e * e;
+    return fma(r1, e2, r1);
+}
+
+// expm1(x) for x <= 0: x = n ln2 + r, |r| <= ln2/2; expm1(r) = r + r^2 q(r) with the degree-11 Taylor q evaluated by
+// Estrin's scheme (depth 5); expm1(x) = 2^n expm1(r) + (2^n - 1).  Relative error ~2e-16 where it matters
+// (small |x|, n = 0); x very negative gives -1.
+__device__ __forceinline__ double expm1_neg(double x)
+{
+    const double nf = __builtin_rint(x * 1.4426950408889634);
+    double r = fma(-nf, 6.93147180369123816490e-01, x);        // ln2 hi / lo (fdlibm split)
+    r = fma(-nf, 1.90821492927058770002e-10, r);
+    const int n = (int)nf;
+    const double s = __builtin_amdgcn_ldexp(1.0, n < -1080 ? -1080 : n);
+    const double sm1 = s - 1.0;
+    const double r2 = r * r;
+    const double a0 = fma(r, 1.0 / 6, 1.0 / 2), a1 = fma(r, 1.0 / 120, 1.0 / 24), a2 = fma(r, 1.0 / 5040, 1.0 / 720);
+    const double a3 = fma(r, 1.0 / 362880, 1.0 / 40320), a4 = fma(r, 1.0 / 39916800, 1.0 / 3628800);
+    const double a5 = fma(r, 1.0 / 6227020800.0, 1.0 / 479001600);
+    const double r4 = r2 * r2;
+    const double b0 = fma(a1, r2, a0), b1 = fma(a3, r2, a2), b2 = fma(a5, r2, a4);
+    const double r8 = r4 * r4;
+    const double q = fma(b2, r8, fma(b1, r4, b0));
+    const double pm = fma(r2, q, r);
+    return fma(s, pm, sm1);
+}
+
+// coth(x) for |x| > 1e-4 from ONE expm1: with em = expm1(-2|x|) in (-1, 0), coth|x| = (2 + em) / (-em).
+__device__ __forceinline__ double coth_gt(double x)
+{
+    const double em = expm1_neg(-2.0 * fabs(x));
+    return copysign((2.0 + em) * rcp_nr(-em), x);
+}
 
 __device__ __forceinline__ double ja_f(double Mn, double Hn, double Hp, const JaParams &p)
 {
-    const double Q = (Hn + p.alpha * Mn) / p.A;
-    const double LQ = fabs(Q) > 1e-4 ? (1.0 / tanh(Q)) - 1.0 / Q : Q / 3.0;
+    const double Q = (Hn + p.alpha * Mn) * p.rA;
+    const double LQ = fabs(Q) > 1e-4 ? coth_gt(Q) - rcp_nr(Q) : Q * (1.0 / 3.0);
     double LpQ;
     // (the reference evaluates L' on L(Q), not on Q: code/tape.py:598-603 -- reproduced)
-    if (fabs(LQ) > 1e-4) { const double ct = 1.0 / tanh(LQ); LpQ = 1.0 / (LQ * LQ) - ct * ct + 1.0; } else LpQ = 1.0 / 3.0;
+    if (fabs(LQ) > 1e-4) { const double ct = coth_gt(LQ); LpQ = rcp_nr(LQ * LQ) - ct * ct + 1.0; } else LpQ = 1.0 / 3.0;
     const double M_diff = p.Ms * LQ - Mn;
     const double dS = Hp > 0.0 ? 1.0 : -1.0;
     const double sgn = M_diff > 0.0 ? 1.0 : (M_diff < 0.0 ? -1.0 : 0.0);
     const double dM = (dS == sgn) ? 1.0 : 0.0;
     const double t1n = (1.0 - p.c) * dM * M_diff;
     const double t1d = (1.0 - p.c) * dS * p.K - p.alpha * M_diff;
-    const double t1 = (t1n / t1d) * Hp;
+    const double t1 = (t1n / t1d) * Hp;                  // IEEE division: t1d may vanish (inf, as in the reference)
     const double t2 = p.c * (p.Ms / p.A) * Hp * LpQ;
-    const double t3 = 1.0 - p.c * p.alpha * (p.Ms / p.A) * LpQ;
-    return (t1 + t2) / t3;
+    const double t3 = 1.0 - p.c * p.alpha * (p.Ms / p.A) * LpQ;     // >= 1 - c alpha Ms / (3 A) > 0 for physical parameters
+    return (t1 + t2) * rcp_nr(t3);
 }
 
 constexpr int JT = 64;   // tile: 64 streams x 64 samples
@@ -33,7 +77,7 @@ constexpr int JT = 64;   // tile: 64 streams x 64 samples
 __global__ __launch_bounds__(64) void tape_hmag_kernel(const double *H, double *M, int64_t B, int64_t N, double *state,
                                                        double Ts, JaParams p)
 {
-#pragma clang fp contract(off)   // keep the reference's operation-by-operation fp64 rounding
+#pragma clang fp contract(off)   // only the explicit fma() calls of the helpers fuse
     __shared__ double tile[JT][JT + 1];
     const int l = threadIdx.x;
     const int64_t s0 = (int64_t)blockIdx.x * JT;
@@ -52,7 +96,7 @@ __global__ __launch_bounds__(64) void tape_hmag_kernel(const double *H, double *
             const double k2 = Ts * ja_f(Mp + k1 / 2.0, (Hn + Hpv) / 2.0, (Hprime + Hpp) / 2.0, p);
             const double k3 = Ts * ja_f(Mp + k2 / 2.0, (Hn + Hpv) / 2.0, (Hprime + Hpp) / 2.0, p);
             const double k4 = Ts * ja_f(Mp + k3, Hn, Hprime, p);
-            double m = Mp + k1 / 6.0 + k2 / 3.0 + k3 / 3.0 + k4 / 6.0;
+            double m = Mp + k1 * (1.0 / 6.0) + k2 * (1.0 / 3.0) + k3 * (1.0 / 3.0) + k4 * (1.0 / 6.0);
             m = m < -p.Ms ? -p.Ms : (m > p.Ms ? p.Ms : m);
             tile[l][n] = m;
             Hpv = Hn; Hpp = Hprime; Mp = m;
@@ -69,7 +113,7 @@ hipError_t launch_tape_hmag(const double *H, double *M, int64_t B, int64_t N, do
                             hipStream_t stream)
 {
     if (B == 0 || N == 0) return hipSuccess;
-    const JaParams p{par[0], par[1], par[2], par[3], par[4]};
+    const JaParams p{par[0], par[1], par[2], par[3], par[4], 1.0 / par[1]};
     hipLaunchKernelGGL(tape_hmag_kernel, dim3((unsigned)((B + JT - 1) / JT)), dim3(64), 0, stream, H, M, B, N, state, Ts, p);
     return hipGetLastError();
 }
