@@ -34,11 +34,13 @@ extern "C" {
 #define NTM_HIDDEN 64 /* the only hidden size compiled (every shipped checkpoint is HS[64]) */
 
 /* GRU kernel variants for ntm_gru_forward_ex:                              */
-#define NTM_GRU_AUTO 0  /* = NTM_GRU_MFMA2                                                  */
+#define NTM_GRU_AUTO 0  /* NTM_GRU_MFMA2, or NTM_GRU_LAT when B <= NTM_GRU_LAT_MAX_B         */
 #define NTM_GRU_MFMA 1  /* 16 streams / workgroup, 4 waves, v_mfma_f32_16x16x4_f32, h in LDS */
 #define NTM_GRU_VALU 2  /* 2 streams / wavefront, W_hh in VGPRs, h broadcast through LDS     */
 #define NTM_GRU_MFMA2 3 /* as MFMA, own-quarter-first step order: LDS exchange hidden by MFMAs */
 #define NTM_GRU_MFMA3 5 /* exact fp32 hybrid: MFMA waves + partner VALU waves on the same SIMDs       */
+#define NTM_GRU_LAT 6   /* exact fp32, ONE stream per workgroup (K split over 4 waves): low latency, small B */
+#define NTM_GRU_LAT_MAX_B 1024
 #define NTM_GRU_F16X3 4 /* OPT-IN: MFMA2 with W.h as three fp16 hi/lo products, fp32 accumulate  */
 
 /* ABI version of this header; bumped on any signature change. */

@@ -53,13 +53,14 @@ int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, 
     if (!w_ih || !w_hh || !b_ih || !b_hh || !w_o || !x || !y) return fail(NTM_EINVAL, "ntm_gru_forward: null pointer");
     if (x_stride_b < T || y_stride_b < T) return fail(NTM_EINVAL, "ntm_gru_forward: stride < T");
     ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, x_stride_b, y_stride_b, nullptr, 0, 0};
-    if (variant == NTM_GRU_AUTO) variant = NTM_GRU_MFMA2;
+    if (variant == NTM_GRU_AUTO) variant = B <= NTM_GRU_LAT_MAX_B ? NTM_GRU_LAT : NTM_GRU_MFMA2;
     hipError_t e;
     switch (variant) {
         case NTM_GRU_MFMA: e = ntm::launch_gru_mfma(a, (hipStream_t)stream); break;
         case NTM_GRU_VALU: e = ntm::launch_gru_valu(a, (hipStream_t)stream); break;
         case NTM_GRU_MFMA2: e = ntm::launch_gru_mfma2(a, (hipStream_t)stream); break;
         case NTM_GRU_MFMA3: e = ntm::launch_gru_mfma3(a, (hipStream_t)stream); break;
+        case NTM_GRU_LAT: e = ntm::launch_gru_lat(a, (hipStream_t)stream); break;
         case NTM_GRU_F16X3: a.engine = 1; e = ntm::launch_gru_mfma2(a, (hipStream_t)stream); break;
         default: return fail(NTM_EINVAL, "ntm_gru_forward: unknown kernel variant");
     }

@@ -43,5 +43,6 @@ hipError_t launch_gru_mfma(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_valu(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_mfma3(const GruArgs &a, hipStream_t stream);
+hipError_t launch_gru_lat(const GruArgs &a, hipStream_t stream);
 hipError_t launch_debug_transpose(const float *in, float *out, hipStream_t stream);
 }  // namespace ntm
