@@ -267,6 +267,13 @@ def main():
         lm["MultiSTFT_f16x3_vs_exact_mean"] = float(r.mean())
         extra["loss_pass"] = lm
         del y2
+    # achievable HBM rate on this box (state it beside the 8 TB/s vendor peak): device copy of the
+    # input batch, read + write bytes over the event time
+    cp = torch.empty_like(x)
+    for _ in range(3):
+        ev0.record(); cp.copy_(x); ev1.record(); torch.cuda.synchronize()
+    hbm_copy_gbs = 2.0 * x.numel() * 4 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+    del cp
     if rank != 0:
         return
     total_samples = float(B) * T * world * a.steps
@@ -309,7 +316,8 @@ def main():
                                 "valu": "gru_valu_kernel", "f16x3": "gru_mfma2_kernel<f16x3>"}[a.variant],
                      "kernel_ms": 1e3 * kern_s, "flop_per_sample": flop_per_sample,
                      "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": hbm_gbs / PEAK_HBM_GBS, "bytes_per_sample": BYTES_PER_SAMPLE}},
+                             "frac": hbm_gbs / PEAK_HBM_GBS, "bytes_per_sample": BYTES_PER_SAMPLE,
+                             "copy_kernel_measured": hbm_copy_gbs}},
         "checks": checks,
     }
     if extra:
