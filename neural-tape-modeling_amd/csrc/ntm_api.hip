@@ -52,6 +52,8 @@ int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, 
     if (B == 0 || T == 0) return NTM_OK;
     if (!w_ih || !w_hh || !b_ih || !b_hh || !w_o || !x || !y) return fail(NTM_EINVAL, "ntm_gru_forward: null pointer");
     if (x_stride_b < T || y_stride_b < T) return fail(NTM_EINVAL, "ntm_gru_forward: stride < T");
+    if (variant == NTM_GRU_VALU && (reinterpret_cast<uintptr_t>(w_hh) & 15))
+        return fail(NTM_EINVAL, "ntm_gru_forward: NTM_GRU_VALU reads W_hh with 16-byte loads; w_hh must be 16-byte aligned");
     ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, x_stride_b, y_stride_b, nullptr, 0, 0};
     if (variant == NTM_GRU_AUTO) variant = B <= NTM_GRU_LAT_MAX_B ? NTM_GRU_LAT : NTM_GRU_MFMA2;
     hipError_t e;
@@ -206,6 +208,8 @@ int ntm_tcn_forward(const float *params, int L, int C, int K, const int *dil, co
     if (C != 32 || K != 13) return fail(NTM_EINVAL, "ntm_tcn_forward: only C = 32 channels, K = 13 taps is compiled");
     if (B == 0 || T == 0) return NTM_OK;
     if (!params || !dil || !x || !y || !scratch) return fail(NTM_EINVAL, "ntm_tcn_forward: null pointer");
+    if ((reinterpret_cast<uintptr_t>(params) & 15) || (reinterpret_cast<uintptr_t>(scratch) & 15))
+        return fail(NTM_EINVAL, "ntm_tcn_forward: params and scratch must be 16-byte aligned");
     hipError_t e = ntm::launch_tcn(params, L, C, K, dil, x, y, B, T, scratch, (hipStream_t)stream);
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_tcn_forward");
 }

@@ -613,3 +613,17 @@ def test_feeder_demodulated_targets(ntm, tmp_path):
         assert t.shape == (2, 14000 - cut) and x.shape == (2, 14000 - cut)
         assert np.array_equal(t.numpy(), want.astype(np.float32))
         assert len(meta["delay_trajectory"]) == 14000 - cut and np.array_equal(meta["output_peaks"], meta["input_peaks"])
+
+
+def test_abi_alignment_checks(ntm):
+    """Kernels that use 16-byte loads on caller memory refuse misaligned pointers instead of faulting."""
+    import ctypes
+    L = ntm._lib.lib()
+    buf = torch.zeros(200000, device="cuda")
+    p = lambda off: ctypes.c_void_p(buf.data_ptr() + 4 * off)       # noqa: E731
+    dil = (ctypes.c_int * 1)(1)
+    rc = L.ntm_tcn_forward(p(1), 1, 32, 13, dil, p(4096), p(8192), 1, 64, p(16384), None)
+    assert rc != 0 and b"aligned" in L.ntm_last_error()
+    rc = L.ntm_gru_forward_ex(p(0), p(1025), p(256), p(512), p(768), None, 64, p(20000), p(30000), 2, 16, 16, 16, None,
+                              ntm._lib.VARIANTS["valu"], None)
+    assert rc != 0 and b"aligned" in L.ntm_last_error()
