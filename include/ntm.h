@@ -155,6 +155,15 @@ int ntm_stft_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t 
                   int win_length, float power_eps, int chunks, double *out, void *stream);
 
 /*
+ * "Next" row N2 plumbing: pitched asynchronous copy between (pinned) host memory and the device, rows x
+ * width_bytes with independent pitches -- what the segment feeder uses to send a TIME CHUNK of many segments
+ * ([B, c0:c1] of a [B,T] batch) so that the copy of chunk c+1 overlaps the GRU launch on chunk c.
+ * kind 0: host -> device, 1: device -> host.  Thin wrapper of hipMemcpy2DAsync on `stream`.
+ */
+int ntm_copy2d_async(void *dst, int64_t dst_pitch_bytes, const void *src, int64_t src_pitch_bytes,
+                     int64_t width_bytes, int64_t rows, int kind, void *stream);
+
+/*
  * "Next" row N3: DelayAnalyzer.demodulate, code/utilities/utilities.py:408-465 -- removes the time-varying
  * delay of a recording using the pulse indices of its pilot channel.  x, out: [C,N] fp32 device (out must not
  * alias x); y_idx [P] int64 device = output pulse indices (strictly increasing, P >= 2);

@@ -171,6 +171,20 @@ int ntm_stft_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t 
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_stft_sums");
 }
 
+int ntm_copy2d_async(void *dst, int64_t dst_pitch_bytes, const void *src, int64_t src_pitch_bytes, int64_t width_bytes,
+                     int64_t rows, int kind, void *stream)
+{
+    if (width_bytes < 0 || rows < 0 || dst_pitch_bytes < width_bytes || src_pitch_bytes < width_bytes)
+        return fail(NTM_EINVAL, "ntm_copy2d_async: bad size or pitch");
+    if (kind != 0 && kind != 1) return fail(NTM_EINVAL, "ntm_copy2d_async: kind must be 0 (H2D) or 1 (D2H)");
+    if (width_bytes == 0 || rows == 0) return NTM_OK;
+    if (!dst || !src) return fail(NTM_EINVAL, "ntm_copy2d_async: null pointer");
+    hipError_t e = hipMemcpy2DAsync(dst, (size_t)dst_pitch_bytes, src, (size_t)src_pitch_bytes, (size_t)width_bytes,
+                                    (size_t)rows, kind == 0 ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost,
+                                    (hipStream_t)stream);
+    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_copy2d_async");
+}
+
 int ntm_demodulate(const float *x, float *out, int C, int64_t N, const int64_t *y_idx, int P, int64_t period, int64_t shift,
                    double *scratch, void *stream)
 {

@@ -146,7 +146,11 @@ class SegmentFeeder:
                 self.mean_delay += float(np.mean(d["delay_trajectory"]))
                 self.max_delay = max(self.max_delay, float(np.max(d["delay_trajectory"])))
                 self.min_delay = min(self.min_delay, float(np.min(d["delay_trajectory"])))
-            self._audio.append((x, t, d))
+            # whole files live in PINNED host memory when a HIP device is present: a batch then goes to the device
+            # as a few large DMA copies straight from here (no per-batch staging copy on the host)
+            if d is not None:
+                d["traj_f32"] = self._host(np.ascontiguousarray(d["delay_trajectory"], np.float32)[None, :])
+            self._audio.append((self._host(x), None if t is None else self._host(t), d))
             start = int(self.sync * self.fs)
             for n_chunk in range((num_frames - start) // self.length):
                 self.examples.append({"idx": idx, "offset": n_chunk * self.length + start})
@@ -154,6 +158,16 @@ class SegmentFeeder:
         self.mean_delay = self.mean_delay / n_traj if n_traj else 0.0               # utilities.py:341
         assert not (demodulate and n_traj != len(self._audio)), "Can't demodulate without trajectory side-cars!"
         self.minutes = self.length * len(self.examples) / self.fs / 60
+
+    @staticmethod
+    def _host(a):
+        t = torch.from_numpy(a)
+        if torch.cuda.is_available():
+            try:
+                return t.pin_memory()
+            except RuntimeError:          # not enough pinnable memory: pageable copies still work
+                return t
+        return t
 
     def __len__(self):
         return len(self.examples)
@@ -164,11 +178,11 @@ class SegmentFeeder:
         o, e = ex["offset"], ex["offset"] + self.length
         name = lambda p: "{0}_[{2}:{3}]{1}".format(*os.path.splitext(os.path.basename(p)), o, e)   # noqa: E731
         meta = {"input_name": name(self.input_files[ex["idx"]])}
-        inp = torch.from_numpy(x[:, o:e])
+        inp = x[:, o:e]
         if self.input_only:
             return inp, meta
         meta["target_name"] = name(self.target_files[ex["idx"]])
-        tgt = torch.from_numpy(t[:, o:e])
+        tgt = t[:, o:e]
         if d is not None:
             T_delay = torch.from_numpy(d["delay_trajectory"][o:e].astype(np.float32))
             pin, pout = segment_peaks(d["input_peaks"], d["output_peaks"], o, e, self.length)
@@ -183,26 +197,146 @@ class SegmentFeeder:
             meta["input_peaks"], meta["output_peaks"] = pin, pout
         return inp, tgt, meta
 
-    def batches(self, batch_size, device="cuda", rank=0, world=1):
+    def runs(self, b0, b1):
+        """Segments b0..b1-1 as runs of consecutive segments of one file: [(first row, n segments, file idx, offset)]."""
+        out, k, L = [], b0, self.length
+        while k < b1:
+            ex = self.examples[k]
+            r = k + 1
+            while r < b1 and self.examples[r]["idx"] == ex["idx"] and self.examples[r]["offset"] == ex["offset"] + (r - k) * L:
+                r += 1
+            out.append((k - b0, r - k, ex["idx"], ex["offset"]))
+            k = r
+        return out
+
+    @torch.no_grad()
+    def predict_streamed(self, model, b0, b1, chunk=8192, device="cuda"):
+        """GRU predict over segments b0..b1-1 straight from pinned host memory, pipelined along TIME: the batch goes to
+        the device in chunks of `chunk` samples x all segments (pitched DMA copies, ntm_copy2d_async, on a side stream)
+        and the kernel for chunk c runs while chunk c+1 is in flight -- every launch still sees the full batch (the
+        matrix-pipe kernel needs thousands of streams per launch; splitting the batch by segments instead would starve
+        it).  State is carried between the launches, so the result is bit-identical to one launch.
+        -> (output (B,1,L), input (B,1,L), target (B,1,L) | None), all on `device`."""
+        assert not self.demodulate, "demodulated targets take the per-item path (batches())"
+        B, L = b1 - b0, self.length
+        lib = _lib.lib()
+        x = torch.empty(B, 1, L, device=device, dtype=torch.float32)
+        t = None if self.input_only else torch.empty(B, 1, L, device=device, dtype=torch.float32)
+        y = torch.empty(B, 1, L, device=device, dtype=torch.float32)
+        runs = self.runs(b0, b1)
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(cur)                                   # the fresh buffers belong to the compute stream
+
+        def send(c0, c1):
+            for k0, n, idx, off in runs:
+                for which, dst in ((0, x), (1, t)):
+                    if dst is None:
+                        continue
+                    src = self._audio[idx][which]
+                    rc = lib.ntm_copy2d_async(dst[k0, 0, c0:].data_ptr(), 4 * L, src[0, off + c0:].data_ptr(), 4 * L,
+                                              4 * (c1 - c0), n, 0, side.cuda_stream)
+                    _lib.check(rc, "ntm_copy2d_async")
+            ev = torch.cuda.Event()
+            ev.record(side)
+            return ev
+
+        model.initialize_hidden()
+        model.warm_start()
+        if B != 1:
+            model.hidden = model.hidden.expand(1, B, model.hidden_size).contiguous()
+        bounds = [(c0, min(L, c0 + chunk)) for c0 in range(0, L, chunk)]
+        ev = send(*bounds[0])
+        for i, (c0, c1) in enumerate(bounds):
+            nxt = send(*bounds[i + 1]) if i + 1 < len(bounds) else None
+            cur.wait_event(ev)
+            model.forward_into(x[:, 0, c0:c1], y[:, 0, c0:c1])
+            ev = nxt
+        for a in (x, t):
+            if a is not None:
+                a.record_stream(side)
+        return y, x, t
+
+    def batches(self, batch_size, device="cuda", rank=0, world=1, prefetch=True):
         """Yield (input (B,1,L), target (B,1,L) | None, d_traj_seconds (B,1,L) | None, metas) on `device`
-        for this rank's contiguous shard of the segments; host staging buffers are pinned when possible."""
+        for this rank's contiguous shard of the segments.  On a HIP device consecutive segments of a file are
+        one contiguous run of pinned host memory, so a batch is a handful of large async DMA copies issued on a
+        side stream while the caller still computes on the previous batch (`prefetch`); the consumer's stream only
+        waits for the copy event of the batch it is handed.  (Demodulated targets take the per-item path.)"""
         from .distributed import shard_range
         lo, hi = shard_range(len(self), rank, world)
-        pin = torch.cuda.is_available()
-        for b0 in range(lo, hi, batch_size):
+        on_gpu = torch.cuda.is_available() and torch.device(device).type == "cuda"
+        copy_stream = torch.cuda.Stream(device=device) if (on_gpu and prefetch) else None
+        L = self.length
+
+        def fill(dst, which, b0, b1):
+            """dst (n,1,L) device tensor <- channel 0 of segments b0..b1-1, one copy per run of consecutive segments."""
+            k = b0
+            while k < b1:
+                ex = self.examples[k]
+                r = k + 1
+                while r < b1 and self.examples[r]["idx"] == ex["idx"] and \
+                        self.examples[r]["offset"] == ex["offset"] + (r - k) * L:
+                    r += 1
+                src = self._audio[ex["idx"]][which]
+                if which == 2:
+                    src = src["traj_f32"]
+                src = src[0, ex["offset"]:ex["offset"] + (r - k) * L]
+                dst[k - b0:r - b0, 0].copy_(src.view(r - k, L), non_blocking=on_gpu)
+                k = r
+
+        def meta_of(i):
+            ex = self.examples[i]
+            o, e = ex["offset"], ex["offset"] + L
+            name = lambda p: "{0}_[{2}:{3}]{1}".format(*os.path.splitext(os.path.basename(p)), o, e)   # noqa: E731
+            m = {"input_name": name(self.input_files[ex["idx"]])}
+            if not self.input_only:
+                m["target_name"] = name(self.target_files[ex["idx"]])
+            return m
+
+        def stage_fast(b0):
+            b1 = min(hi, b0 + batch_size)
+            has_d = all(self._audio[self.examples[i]["idx"]][2] is not None for i in range(b0, b1))
+            out = [torch.empty(b1 - b0, 1, L, device=device, dtype=torch.float32),
+                   None if self.input_only else torch.empty(b1 - b0, 1, L, device=device, dtype=torch.float32),
+                   torch.empty(b1 - b0, 1, L, device=device, dtype=torch.float32) if has_d else None]
+            for which, dst in enumerate(out):
+                if dst is not None:
+                    fill(dst, which, b0, b1)
+            return out, [meta_of(i) for i in range(b0, b1)], None
+
+        def stage_items(b0):
             items = [self[i] for i in range(b0, min(hi, b0 + batch_size))]
             stack = lambda k: torch.stack([it[k][:1] for it in items])                # noqa: E731  audio = channel 0
-            xin = stack(0)
-            tgt = None if self.input_only else stack(1)
             metas = [{k: v for k, v in it[-1].items() if not k.endswith("_peaks")} for it in items]
             dt = None
             if all("delay_trajectory" in m for m in metas):
                 dt = torch.stack([m["delay_trajectory"] for m in metas]).unsqueeze(1)
-            out = []
-            for a in (xin, tgt, dt):
-                if a is None:
-                    out.append(None)
-                    continue
-                a = a.pin_memory() if pin else a
-                out.append(a.to(device, non_blocking=True))
+            host = [stack(0), None if self.input_only else stack(1), dt]
+            host = [a.pin_memory() if (a is not None and on_gpu) else a for a in host]
+            return [None if a is None else a.to(device, non_blocking=on_gpu) for a in host], metas, host
+
+        def stage(b0):
+            fn = stage_items if self.demodulate else stage_fast
+            if copy_stream is None:
+                out, metas, keep = fn(b0)
+                return out, metas, None, keep
+            with torch.cuda.stream(copy_stream):
+                out, metas, keep = fn(b0)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            return out, metas, ev, keep          # `keep` holds pinned staging buffers alive until the batch is consumed
+
+        starts = list(range(lo, hi, batch_size))
+        nxt = stage(starts[0]) if starts else None
+        for k in range(len(starts)):
+            out, metas, ev, keep = nxt
+            nxt = stage(starts[k + 1]) if k + 1 < len(starts) else None
+            if ev is not None:
+                cur = torch.cuda.current_stream()
+                cur.wait_event(ev)
+                for a in out:
+                    if a is not None:
+                        a.record_stream(cur)
             yield out[0], out[1], out[2], metas
+            del keep

@@ -104,6 +104,29 @@ class _GRUHead(torch.nn.Module):
         self.hidden = h
         return y
 
+    @torch.no_grad()
+    def forward_into(self, x2d, y2d):
+        """Stateful forward on ROW-STRIDED [B,Tc] fp32 views (unit stride along time), e.g. the time chunk
+        `x[:, 0, c0:c1]` of a resident (B,1,T) batch, written into the matching view of the output -- the C ABI
+        takes row strides, so a chunked / streamed predict needs no gather or scatter copies."""
+        for t, what in ((x2d, "input"), (y2d, "output")):
+            _require_hip(t, f"forward_into {what}")
+            if t.dim() != 2 or t.dtype != torch.float32 or (t.shape[1] > 1 and t.stride(1) != 1):
+                raise RuntimeError(f"forward_into: {what} must be a 2-D float32 view with unit stride along time")
+        if x2d.shape != y2d.shape:
+            raise RuntimeError("forward_into: shape mismatch")
+        B, T = x2d.shape
+        h = self._hidden_for(B, x2d.device)
+        g, o = self.GRU, self.output
+        rc = _lib.lib().ntm_gru_forward_ex(
+            ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0), ptr(o.weight),
+            ptr(o.bias), self.hidden_size, ptr(x2d), ptr(y2d), B, T, max(x2d.stride(0), T), max(y2d.stride(0), T), ptr(h),
+            _lib.VARIANTS[self.kernel_variant], _lib.current_stream())
+        _lib.check(rc, "ntm_gru_forward")
+        self.hidden = h
+        if self.skip:
+            y2d += x2d
+
 
 class RNN(_GRUHead):
     """GRU + fully connected output layer (reference: code/model.py:20-246)."""

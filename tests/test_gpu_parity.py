@@ -627,3 +627,31 @@ def test_abi_alignment_checks(ntm):
     rc = L.ntm_gru_forward_ex(p(0), p(1025), p(256), p(512), p(768), None, 64, p(20000), p(30000), 2, 16, 16, 16, None,
                               ntm._lib.VARIANTS["valu"], None)
     assert rc != 0 and b"aligned" in L.ntm_last_error()
+
+
+def test_streamed_predict_from_pinned_host(ntm, tmp_path):
+    """N2: time-pipelined predict straight from the feeder's pinned files (pitched DMA chunks on a side stream, the
+    GRU launch per chunk on the compute stream, state carried) == one resident launch, bit for bit; input and
+    target arrive intact; runs of consecutive segments are found across file boundaries."""
+    from scipy.io import wavfile
+    from ntm_amd.feeder import SegmentFeeder
+    d = tmp_path / "Set" / "Test"
+    d.mkdir(parents=True)
+    rng = np.random.default_rng(3)
+    L = 3000
+    for i, nseg in enumerate((3, 1, 4)):
+        x = (rng.uniform(-0.5, 0.5, nseg * L + 17 * i) * 32767).astype(np.int16)
+        wavfile.write(str(d / f"input_{i}_.wav"), 44100, x)
+        wavfile.write(str(d / f"target_{i}_.wav"), 44100, (0.5 * x).astype(np.int16))
+    f = SegmentFeeder(str(tmp_path / "Set"), subset="test", length=L)
+    assert len(f) == 8 and [r[:2] for r in f.runs(1, 8)] == [(0, 2), (2, 1), (3, 4)]
+    m = make_rnn(ntm, W_G, "mfma2")
+    xin, tgt, _, _ = next(f.batches(8, "cuda"))
+    want = m.predict(xin)
+    for chunk in (1000, 700, 3000, 8192):
+        y, x2, t2 = f.predict_streamed(m, 0, 8, chunk=chunk)
+        torch.cuda.synchronize()
+        assert torch.equal(x2, xin) and torch.equal(t2, tgt), chunk
+        assert torch.equal(y, want), chunk
+    y, x2, _ = f.predict_streamed(m, 2, 7, chunk=512)          # a sub-range that starts inside a file
+    assert torch.equal(x2, xin[2:7]) and torch.equal(y, m.predict(xin[2:7]))

@@ -30,7 +30,8 @@ def main(argv=None):
     p.add_argument('--WEIGHTS', type=str, required=True)
     p.add_argument('--SEGMENT_LENGTH', type=int, default=None)
     p.add_argument('--SYNC', type=float, default=0.0)
-    p.add_argument('--BATCH_SIZE', type=int, default=64)
+    p.add_argument('--BATCH_SIZE', type=int, default=4096, help="segments per launch (the matrix-pipe kernel wants thousands)")
+    p.add_argument('--STREAM_CHUNK', type=int, default=8192, help="time chunk of the host->device pipeline; 0 = whole-batch copies")
     p.add_argument('--MAX_DELAY', type=float, default=0.0, help="seconds (DelayAnalyzer.max_delay of the dataset)")
     p.add_argument('--COMPUTE_LOSS', action='store_true', default=False)
     p.add_argument('--DEMODULATE', action='store_true', default=False)
@@ -55,12 +56,23 @@ def main(argv=None):
         return {}
     per = {"ESR": [], "DCPreESR": [], "MultiSTFT": []}
     mrstft = ntm_amd.MRSTFTLoss()
-    for xin, tgt, dt, _ in feeder.batches(a.BATCH_SIZE, "cuda", rank, world):
-        if is_dd:
-            assert dt is not None, "DiffDelGRU needs trajectory_<id>_*.npy side-cars"
-            out, _ = model.predict(xin, dt * feeder.fs)
+    def batches():
+        if is_dd or a.DEMODULATE or a.STREAM_CHUNK <= 0:
+            for xin, tgt, dt, _ in feeder.batches(a.BATCH_SIZE, "cuda", rank, world):
+                if is_dd:
+                    assert dt is not None, "DiffDelGRU needs trajectory_<id>_*.npy side-cars"
+                    out, _ = model.predict(xin, dt * feeder.fs)
+                else:
+                    out = model.predict(xin)
+                yield xin, tgt, out
         else:
-            out = model.predict(xin)
+            # GRU: predict straight from the feeder's pinned files, H2D copies pipelined along time under the launches
+            lo, hi = D.shard_range(len(feeder), rank, world)
+            for b0 in range(lo, hi, a.BATCH_SIZE):
+                out, xin, tgt = feeder.predict_streamed(model, b0, min(hi, b0 + a.BATCH_SIZE), chunk=a.STREAM_CHUNK)
+                yield xin, tgt, out
+
+    for xin, tgt, out in batches():
         n = xin.shape[-1] - init_len
         for key, fn in (("ESR", esr_sums), ("DCPreESR", esr_dcpre_sums)):
             s = fn(out, tgt, skip=init_len)
