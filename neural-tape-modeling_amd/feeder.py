@@ -210,12 +210,15 @@ class SegmentFeeder:
         return out
 
     @torch.no_grad()
-    def predict_streamed(self, model, b0, b1, chunk=8192, device="cuda"):
+    def predict_streamed(self, model, b0, b1, chunk=8192, device="cuda", out_host=None):
         """GRU predict over segments b0..b1-1 straight from pinned host memory, pipelined along TIME: the batch goes to
         the device in chunks of `chunk` samples x all segments (pitched DMA copies, ntm_copy2d_async, on a side stream)
         and the kernel for chunk c runs while chunk c+1 is in flight -- every launch still sees the full batch (the
         matrix-pipe kernel needs thousands of streams per launch; splitting the batch by segments instead would starve
         it).  State is carried between the launches, so the result is bit-identical to one launch.
+        `out_host`: optional pinned (B,1,L) fp32 host tensor; each finished output chunk is copied back on a
+        second side stream while the next chunk computes (host -> device -> host, all three overlapped; the caller
+        synchronises before reading it).
         -> (output (B,1,L), input (B,1,L), target (B,1,L) | None), all on `device`."""
         assert not self.demodulate, "demodulated targets take the per-item path (batches())"
         B, L = b1 - b0, self.length
@@ -247,11 +250,23 @@ class SegmentFeeder:
             model.hidden = model.hidden.expand(1, B, model.hidden_size).contiguous()
         bounds = [(c0, min(L, c0 + chunk)) for c0 in range(0, L, chunk)]
         ev = send(*bounds[0])
+        back = torch.cuda.Stream(device=device) if out_host is not None else None
+        if out_host is not None:
+            assert tuple(out_host.shape) == (B, 1, L) and out_host.dtype == torch.float32 and out_host.is_contiguous()
         for i, (c0, c1) in enumerate(bounds):
             nxt = send(*bounds[i + 1]) if i + 1 < len(bounds) else None
             cur.wait_event(ev)
             model.forward_into(x[:, 0, c0:c1], y[:, 0, c0:c1])
+            if back is not None:
+                done = torch.cuda.Event()
+                done.record(cur)
+                back.wait_event(done)
+                rc = lib.ntm_copy2d_async(out_host[0, 0, c0:].data_ptr(), 4 * L, y[0, 0, c0:].data_ptr(), 4 * L,
+                                          4 * (c1 - c0), B, 1, back.cuda_stream)
+                _lib.check(rc, "ntm_copy2d_async")
             ev = nxt
+        if back is not None:
+            cur.wait_stream(back)                               # a sync of the caller's stream covers the copies back
         for a in (x, t):
             if a is not None:
                 a.record_stream(side)

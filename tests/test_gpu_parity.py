@@ -653,5 +653,9 @@ def test_streamed_predict_from_pinned_host(ntm, tmp_path):
         torch.cuda.synchronize()
         assert torch.equal(x2, xin) and torch.equal(t2, tgt), chunk
         assert torch.equal(y, want), chunk
+    host = torch.empty(8, 1, L).pin_memory()
+    y, _, _ = f.predict_streamed(m, 0, 8, chunk=900, out_host=host)          # results copied back as they are produced
+    torch.cuda.synchronize()
+    assert torch.equal(host, want.cpu())
     y, x2, _ = f.predict_streamed(m, 2, 7, chunk=512)          # a sub-range that starts inside a file
     assert torch.equal(x2, xin[2:7]) and torch.equal(y, m.predict(xin[2:7]))

@@ -36,4 +36,10 @@ for rep in range(3):
         tot = float(esr_sums(y, tgt, 1024)[:, 0].sum())
         torch.cuda.synchronize(); dt = time.time() - t0
         print(f"streamed, one batch of {len(f)}, time chunks of {chunk}: {dt*1e3:.0f} ms = {len(f)*L/dt/1e9:.2f} Gsamples/s end to end from host memory")
+host = torch.empty(len(f), 1, L).pin_memory()
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.time()
+    y, xin, tgt = f.predict_streamed(m, 0, len(f), chunk=8192, out_host=host)
+    torch.cuda.synchronize(); dt = time.time() - t0
+    print(f"streamed host -> device -> host (output copied back per chunk): {dt*1e3:.0f} ms = {len(f)*L/dt/1e9:.2f} Gsamples/s")
 import shutil; shutil.rmtree(root)
