@@ -659,3 +659,22 @@ def test_streamed_predict_from_pinned_host(ntm, tmp_path):
     assert torch.equal(host, want.cpu())
     y, x2, _ = f.predict_streamed(m, 2, 7, chunk=512)          # a sub-range that starts inside a file
     assert torch.equal(x2, xin[2:7]) and torch.equal(y, m.predict(xin[2:7]))
+
+
+def test_random_shapes_all_exact_kernels_agree_with_oracle(ntm):
+    """Seeded sweep over ragged shapes (tile edges of every kernel: 16 streams per MFMA group, 64- and 256-sample
+    tiles, 2048-sample chunks) with a carried random state: every exact-fp32 kernel against the oracle."""
+    rng = np.random.default_rng(2024)
+    w = oracle_weights(W_G)
+    shapes = [(1, 1), (1, 63), (1, 257), (2, 64), (3, 65), (15, 129), (16, 256), (17, 255), (31, 511), (33, 513),
+              (64, 100), (100, 7), (129, 300), (255, 66), (5, 2049), (1025, 70)]
+    for B, T in shapes:
+        x = rng.uniform(-0.6, 0.6, (B, T)).astype(np.float32)
+        h0 = rng.uniform(-0.9, 0.9, (B, 64)).astype(np.float32)
+        yo, ho = oracle.gru_forward(w, x, h0.copy(), threads=4)
+        for variant in ("auto", "lat", "mfma2", "mfma", "valu"):
+            m = make_rnn(ntm, W_G, variant)
+            m.hidden = dev(h0).unsqueeze(0)
+            y = m(dev(x).unsqueeze(1)).cpu().numpy()[:, 0]
+            assert np.abs(y - yo).max() < TOL, (variant, B, T)
+            assert np.abs(m.hidden.cpu().numpy()[0] - ho).max() < TOL, (variant, B, T)
