@@ -68,7 +68,7 @@ def _as_bt(x, what):
 class _GRUHead(torch.nn.Module):
     """GRU(1,H) + Linear(H,1[,bias]) state and launch logic shared by RNN and DiffDelRNN."""
 
-    kernel_variant = "auto"      # "auto" | "mfma" | "valu"  (see include/ntm.h NTM_GRU_*)
+    kernel_variant = "auto"      # "auto" | "mfma2" | "lat" | "f16x3" | "mfma" | "valu" | "mfma3"  (include/ntm.h NTM_GRU_*)
 
     def _init_net(self, input_size, hidden_size, output_size, skip, head_bias):
         if input_size != 1 or output_size != 1:
