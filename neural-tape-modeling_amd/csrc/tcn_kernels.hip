@@ -46,6 +46,46 @@ __global__ __launch_bounds__(256) void tcn_first_kernel(const float *x, float *o
     *(f32x4 *)(out + (b * T + n) * TC + 4 * c4) = v;
 }
 
+// ---- first block, dilation 1 (the frozen spec): thread -> (8 consecutive samples, group of 4 output channels) --
+// The 8 samples share a window of 20 inputs (loaded once, 13 x 8 in the generic kernel) and the 13 weight
+// vectors stay in registers; the kernel then runs at the rate of its 34 GB of output.  Same operation order per
+// output as the generic kernel (bit-identical results).
+__global__ __launch_bounds__(256) void tcn_first_d1_kernel(const float *x, float *out, const float *W, const float *bias,
+                                                           const float *alpha, const float *R, int64_t T)
+{
+    constexpr int S = 8;
+    const int64_t b = blockIdx.x;
+    const int c4 = threadIdx.x & 7;
+    const int64_t n0 = ((int64_t)blockIdx.y * 32 + (threadIdx.x >> 3)) * S;
+    if (n0 >= T) return;
+    const float *xb = x + b * T;
+    float xw[S + TK - 1];
+#pragma unroll
+    for (int i = 0; i < S + TK - 1; ++i) {
+        const int64_t src = n0 - (TK - 1) + i;
+        xw[i] = (src >= 0 && src < T) ? xb[src] : 0.0f;
+    }
+    f32x4 wv[TK];
+#pragma unroll
+    for (int k = 0; k < TK; ++k) wv[k] = *(const f32x4 *)(W + k * TC + 4 * c4);
+    const f32x4 bi = *(const f32x4 *)(bias + 4 * c4), al = *(const f32x4 *)(alpha + 4 * c4), rv = *(const f32x4 *)(R + 4 * c4);
+    float *ob = out + (b * T + n0) * TC + 4 * c4;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (n0 + s >= T) break;
+        f32x4 acc = bi;
+#pragma unroll
+        for (int k = 0; k < TK; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(wv[k][e], xw[s + k], acc[e]);
+        const float x0 = xw[s + TK - 1];
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(rv[e], x0, acc[e] >= 0.0f ? acc[e] : al[e] * acc[e]);
+        *(f32x4 *)(ob + (int64_t)s * TC) = v;
+    }
+}
+
 // ---- 32 -> 32 channel block, polyphase tile order + LDS staging (the one launch_tcn uses) -------------
 // A tile is 16 outputs of ONE phase of the dilation: n = p + (m0 + j) dil, j = 0..15.  Its 13 taps read the
 // rows m0 + j + k - 12 of the same phase, so consecutive taps reuse the same 28 input rows: they are staged
@@ -60,12 +100,19 @@ constexpr int TILE_F = TROWS * TRS;        // 1008 floats per tile window
 constexpr int TPW = 512;                   // tiles per workgroup
 constexpr int TCN2_SMEM_FLOATS = 2 * 2 * 4 * TILE_F;   // [buffer][pair][tile]  = 64 512 B
 
+// FUSE_OUT (the last block): the 1x1 output conv y[n] = ob + sum_c ow[c] act[n][c] is applied to the tile while it
+// is still in registers -- lane partial over its 4 channels, two cross-lane adds over the 4 lane groups, the
+// two waves of a pair (channel halves) meet through LDS behind the iteration's barrier -- and the [B][T][32]
+// activation of the last block is never written or read back (2 x 34 GB at 4096 x 65 536).
+template <bool FUSE_OUT>
 __global__ __launch_bounds__(256, 1) void tcn_block_mfma2_kernel(const float *in, float *out, const float *W,
                                                                  const float *bias, const float *alpha,
                                                                  const float *R, int dil, int64_t T, int tpp,
-                                                                 int total_tiles)
+                                                                 int total_tiles, const float *ow, const float *obias,
+                                                                 float *yout)
 {
     extern __shared__ __attribute__((aligned(16))) float tsm[];
+    __shared__ float ypp[2][2][4][16];        // FUSE_OUT: [iteration parity][pair][tile][sample] partial of wave mt = 1
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mt = w & 1, ng = w >> 1;
@@ -84,9 +131,26 @@ __global__ __launch_bounds__(256, 1) void tcn_block_mfma2_kernel(const float *in
         for (int s = 0; s < 8; ++s) Aw[k][s] = W[((8 * q + s) * TK + k) * TC + 16 * mt + j];
 #pragma unroll
     for (int s = 0; s < 8; ++s) Ar[s] = R[(8 * q + s) * TC + 16 * mt + j];
-    f32x4 bi, al;
+    f32x4 bi, al, owv = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int v = 0; v < 4; ++v) { bi[v] = bias[16 * mt + 4 * q + v]; al[v] = alpha[16 * mt + 4 * q + v]; }
+    if constexpr (FUSE_OUT) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) owv[v] = ow[16 * mt + 4 * q + v];
+    }
+    float ypart[4] = {0.0f, 0.0f, 0.0f, 0.0f};      // FUSE_OUT, wave mt = 0: own half of the last iteration's outputs
+    int64_t yn[4] = {T, T, T, T};
+    float *yb = FUSE_OUT ? yout + b * T : nullptr;
+    const float ob0 = FUSE_OUT ? obias[0] : 0.0f;
+    auto finish_y = [&](int parity) {              // after the barrier: wave mt = 0 adds the other half and stores
+        if constexpr (FUSE_OUT) {
+            if (mt == 0 && q == 0) {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    if (yn[nt] < T) yb[yn[nt]] = (ypart[nt] + ypp[parity][ng][nt][j]) + ob0;
+            }
+        }
+    };
 
     // staging: the pair's 4 windows = 112 rows x 8 pieces of 16 B = 896 pieces over its 128 lanes (7 each)
     int st_nt[7], st_roff[7], st_lds[7];
@@ -167,10 +231,19 @@ __global__ __launch_bounds__(256, 1) void tcn_block_mfma2_kernel(const float *in
                 const float u = acc[nt][e];
                 v[e] = (u >= 0.0f ? u : al[e] * u) + res[nt][e];
             }
-            if (n < T) *(f32x4 *)(ob + n * TC + 16 * mt + 4 * q) = v;
+            if constexpr (FUSE_OUT) {
+                float p = (owv[0] * v[0] + owv[1] * v[1]) + (owv[2] * v[2] + owv[3] * v[3]);
+                p += __shfl_xor(p, 16, 64);
+                p += __shfl_xor(p, 32, 64);
+                if (mt == 1) { if (q == 0) ypp[it & 1][ng][nt][j] = p; }
+                else { ypart[nt] = p; yn[nt] = n; }
+            } else {
+                if (n < T) *(f32x4 *)(ob + n * TC + 16 * mt + 4 * q) = v;
+            }
         }
         if (it + 1 < niter) stage_store(buf ^ 1);
         __syncthreads();
+        finish_y(it & 1);
     }
 }
 
@@ -209,7 +282,10 @@ hipError_t launch_tcn(const float *params, int L, int C, int K, const int *dil, 
         const float *alpha = p;  p += C;
         const float *R = p;      p += (size_t)C * cin;
         float *out = (l & 1) ? bufB : bufA;
-        if (cin == 1) hipLaunchKernelGGL(tcn_first_kernel, gridf, dim3(256), 0, stream, in, out, W, bias, alpha, R, dil[l], T);
+        if (cin == 1 && dil[l] == 1)
+            hipLaunchKernelGGL(tcn_first_d1_kernel, dim3((unsigned)B, (unsigned)((T + 255) / 256)), dim3(256), 0, stream, in,
+                               out, W, bias, alpha, R, T);
+        else if (cin == 1) hipLaunchKernelGGL(tcn_first_kernel, gridf, dim3(256), 0, stream, in, out, W, bias, alpha, R, dil[l], T);
         else {
             // polyphase tiles: M = ceil(T / dil) outputs per phase, tpp = ceil(M / 16) tiles per phase
             const int64_t M = (T + dil[l] - 1) / dil[l];
@@ -217,14 +293,19 @@ hipError_t launch_tcn(const float *params, int L, int C, int K, const int *dil, 
             const int64_t total = (int64_t)dil[l] * tpp;
             if (dil[l] <= 0 || total > (int64_t)1 << 30) return hipErrorInvalidValue;
             const dim3 gridp((unsigned)B, (unsigned)((total + TPW - 1) / TPW));
-            hipLaunchKernelGGL(tcn_block_mfma2_kernel, gridp, dim3(256), TCN2_SMEM_FLOATS * sizeof(float), stream, in,
-                               out, W, bias, alpha, R, dil[l], T, tpp, (int)total);
+            if (l == L - 1) {      // last block: 1x1 output conv fused (out_w, out_b follow this block's parameters)
+                hipLaunchKernelGGL(tcn_block_mfma2_kernel<true>, gridp, dim3(256), TCN2_SMEM_FLOATS * sizeof(float), stream,
+                                   in, out, W, bias, alpha, R, dil[l], T, tpp, (int)total, p, p + C, y);
+                return hipGetLastError();
+            }
+            hipLaunchKernelGGL(tcn_block_mfma2_kernel<false>, gridp, dim3(256), TCN2_SMEM_FLOATS * sizeof(float), stream, in,
+                               out, W, bias, alpha, R, dil[l], T, tpp, (int)total, nullptr, nullptr, nullptr);
         }
         in = out;
         cin = C;
     }
     if (cin != C) return hipErrorInvalidValue;   // L == 0
-    hipLaunchKernelGGL(tcn_out_kernel, grid1, dim3(256), 0, stream, in, y, p, p + C, T);
+    hipLaunchKernelGGL(tcn_out_kernel, grid1, dim3(256), 0, stream, in, y, p, p + C, T);   // single-block network
     return hipGetLastError();
 }
 

@@ -347,7 +347,8 @@ def test_harness_compute_loss_gru_and_diffdel(ntm):
 
 
 # ----------------------------------------------------------------------------- TCN (builder-defined)
-@pytest.mark.parametrize("B,T,dil", [(3, 700, (1, 3, 9, 27)), (2, 4000, (1, 10, 100, 1000)), (1, 1, (1, 10, 100, 1000))])
+@pytest.mark.parametrize("B,T,dil", [(3, 700, (1, 3, 9, 27)), (2, 4000, (1, 10, 100, 1000)), (1, 1, (1, 10, 100, 1000)),
+                                     (2, 900, (2, 5, 1, 3)), (2, 300, (1,)), (3, 1030, (1, 7))])
 def test_tcn_vs_oracle(ntm, B, T, dil):
     m = ntm.TCN(dilations=dil).to("cuda")
     rng = np.random.default_rng(B * 7 + T)
