@@ -105,7 +105,7 @@ constexpr int TCN2_SMEM_FLOATS = 2 * 2 * 4 * TILE_F;   // [buffer][pair][tile]  
 // two waves of a pair (channel halves) meet through LDS behind the iteration's barrier -- and the [B][T][32]
 // activation of the last block is never written or read back (2 x 34 GB at 4096 x 65 536).
 template <bool FUSE_OUT>
-__global__ __launch_bounds__(256, 1) void tcn_block_mfma2_kernel(const float *in, float *out, const float *W,
+__global__ __launch_bounds__(256, 2) void tcn_block_mfma2_kernel(const float *in, float *out, const float *W,
                                                                  const float *bias, const float *alpha,
                                                                  const float *R, int dil, int64_t T, int tpp,
                                                                  int total_tiles, const float *ow, const float *obias,
