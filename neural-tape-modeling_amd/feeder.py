@@ -14,8 +14,9 @@ code/test-model.py:323-324 turns into INIT_LEN and the model's delay-line length
 segment (code/dataset.py:262-279) and, with `demodulate=True`, demodulates the targets on the device
 (`demodulate()` below = DelayAnalyzer.demodulate, :408-465) and drops the mean delay from the segment ends
 (code/dataset.py:395-408).
-What is NOT kept (out of scope): the pulse-train ANALYSIS itself (scipy find_peaks heuristics,
-:466-610 -- side-cars must exist), fractional sub-sampling, shuffling, half/double storage.
+Stereo pairs without a side-car are analysed on first use like the reference does (`find_pulses` / `analyze_delay`
+below = code/utilities/utilities.py:343-406, :466-610, pinned by golden g12) and the side-car is written.
+What is NOT kept (out of scope): fractional sub-sampling, shuffling, half/double storage.
 The dataset itself (Zenodo 8026272) is not available here, so this module is checked against synthetic
 files only (tests/test_feeder.py).
 """
@@ -67,6 +68,78 @@ def load_trajectory(path):
     return {"delay_trajectory": np.asarray(a, np.float64), "input_peaks": None, "output_peaks": None}
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Pulse-train analysis (host side, numpy/scipy like the reference): what DelayAnalyzer does the first time it sees a
+# stereo dataset, code/utilities/utilities.py:343-406 (analyze_delay) and :466-610 (_get_pulse_indices).  Only
+# needed when the `trajectory_<id>_*.npy` side-cars are missing; the result is cached in the reference's own
+# side-car format.  Pinned by golden g12 (tools/make_goldens_demod.py calls the reference's methods).
+# ---------------------------------------------------------------------------------------------------------
+def find_pulses(signal, fs, wiggle=True, rel_threshold=0.01, prominence=0.05):
+    """Sample indices of the pilot pulses in `signal` (100 pulses per second nominal), with missing pulses
+    re-inserted at the median period and, if `wiggle`, pulses whose spacing jumps by >= 5 samples re-timed.
+    -> (indices, {"reconstruction_percentage", "wiggle_percentage"})  (code/utilities/utilities.py:466-610)."""
+    import scipy.signal
+    sig = np.asarray(signal).reshape(-1)
+    nominal = fs / 100.0                                   # expected pulse period in samples
+    min_dist, max_width = int(0.9 * nominal), (None, nominal / 2)
+    gap_factor, wiggle_jump, fallout, max_rebuilt = 1.5, 5, 0.5, 5
+    peak = np.max(sig)
+    while True:
+        # the first pulse with a fixed threshold on the rectified signal, the others with the adaptive one
+        first = scipy.signal.find_peaks(np.pad(np.clip(sig, 0, None), (1, 1), 'minimum'), height=peak * 0.01,
+                                        distance=min_dist, prominence=0.01, width=max_width)[0][0] - 1
+        skip = first + int(nominal / 2)
+        rest, _ = scipy.signal.find_peaks(np.pad(sig[skip:], (0, 1), 'minimum'), height=peak * rel_threshold,
+                                          distance=min_dist, prominence=prominence, width=max_width)
+        idx = np.concatenate(([first], rest + skip))
+        period = int(np.median(np.diff(idx)))
+        if not np.isclose(period, nominal, atol=nominal * (gap_factor - 1.0)):
+            rel_threshold *= fallout; prominence *= fallout        # implausible period: look harder
+            continue
+        # re-insert missing pulses, one median period after their predecessor
+        rebuilt = 0
+        gaps = np.where(np.diff(idx) > gap_factor * period)[0]
+        while len(gaps) > 0:
+            n = gaps[0]
+            while idx[n + 1] - idx[n] > gap_factor * period:
+                idx = np.concatenate((idx[:n + 1], [idx[n] + period], idx[n + 1:]))
+                n += 1
+                rebuilt += 1
+            gaps = np.where(np.diff(idx) > gap_factor * period)[0]
+        rebuilt_pct = rebuilt / len(idx) * 100
+        if rebuilt_pct > max_rebuilt:
+            rel_threshold *= fallout; prominence *= fallout        # too many guesses: look harder
+            continue
+        wiggle_pct = 0.0
+        if wiggle:
+            bad = np.where(np.diff(idx, n=2) >= wiggle_jump)[0]
+            idx[bad + 2] = idx[bad + 1] + period
+            wiggle_pct = len(bad) / len(idx) * 100
+        return idx, {"reconstruction_percentage": rebuilt_pct, "wiggle_percentage": wiggle_pct}
+
+
+def analyze_delay(input_pilot, output_pilot, fs, wiggle=True, upsampling="cubic"):
+    """Delay trajectory [seconds, one value per sample] between two pilot pulse trains
+    (code/utilities/utilities.py:343-406): pulse indices of both, their difference at the output pulse times,
+    interpolated to every sample (constant outside the pulses).
+    -> (input_peaks, output_peaks, delay_trajectory, input_meta, output_meta)."""
+    import scipy.interpolate
+    xi, xm = find_pulses(input_pilot, fs, wiggle)
+    yi, ym = find_pulses(output_pilot, fs, wiggle)
+    xi = xi[:len(yi)]
+    yi = yi[:len(xi)]
+    d = (yi - xi) / fs
+    f = scipy.interpolate.interp1d(yi / fs, d, kind=upsampling, fill_value=(d[0], d[-1]), bounds_error=False)
+    n = len(np.asarray(input_pilot).reshape(-1))
+    return xi, yi, f(np.arange(0, n / fs, 1 / fs)), xm, ym
+
+
+def write_sidecar(path, input_peaks, output_peaks, delay_trajectory, input_meta, output_meta):
+    """The reference's side-car: a pickled dict saved with np.save (code/utilities/utilities.py:327-335)."""
+    np.save(path, {"input_peaks": input_peaks, "input_meta": input_meta, "output_peaks": output_peaks,
+                   "output_meta": output_meta, "delay_trajectory": delay_trajectory})
+
+
 def segment_peaks(input_peaks, output_peaks, offset, end, length):
     """Pulse indices of one segment, relative to its start: code/dataset.py:262-279 (including its use of the
     last pulse INDEX VALUE as a slice bound when the segment runs past the last pulse)."""
@@ -104,7 +177,8 @@ def demodulate(output, x_idx_pulse, y_idx_pulse):
 
 
 class SegmentFeeder:
-    def __init__(self, data_dir, subset="train", length=44100, input_only=False, sync=0.0, demodulate=False):
+    def __init__(self, data_dir, subset="train", length=44100, input_only=False, sync=0.0, demodulate=False,
+                 analyze=True, write_sidecars=True):
         assert os.path.exists(data_dir), "Can't find chosen data_dir"
         assert not (input_only and demodulate), "Can't demodulate without inputs"       # code/dataset.py:68
         self.data_dir, self.subset, self.length, self.input_only, self.sync = data_dir, subset, length, input_only, sync
@@ -142,6 +216,18 @@ class SegmentFeeder:
                 if x.shape[-1] != t.shape[-1]:
                     raise RuntimeError("Found potentially corrupt file!")
             d = load_trajectory(traj[_file_id(ifile)]) if _file_id(ifile) in traj else None
+            if d is None and analyze and t is not None and x.shape[0] > 1 and t.shape[0] > 1:
+                # stereo pair without a side-car: analyse the pilot channels as DelayAnalyzer does on first use
+                # (code/utilities/utilities.py:306-335) and cache the result next to the audio in its format
+                xi, yi, T_delay, xm, ym = analyze_delay(x[1].astype(np.float64), t[1].astype(np.float64), fs)
+                if write_sidecars:
+                    name = "trajectory" + os.path.splitext(os.path.basename(ifile).split("input")[1])[0] + ".npy"
+                    try:
+                        write_sidecar(os.path.join(os.path.dirname(ifile), name), xi, yi, T_delay, xm, ym)
+                    except OSError:
+                        pass                                   # read-only dataset: keep the analysis in memory
+                d = {"delay_trajectory": np.asarray(T_delay, np.float64), "input_peaks": xi.astype(np.int64),
+                     "output_peaks": yi.astype(np.int64)}
             if d is not None:                                                          # utilities.py:296-300
                 self.mean_delay += float(np.mean(d["delay_trajectory"]))
                 self.max_delay = max(self.max_delay, float(np.max(d["delay_trajectory"])))

@@ -103,3 +103,39 @@ def test_g11_demodulate_oracle_is_the_reference():
     for i in range(int(g["n"])):
         dem = oracle.demodulate(g[f"out{i}"], g[f"x{i}"], g[f"y{i}"])
         assert np.array_equal(dem, g[f"dem{i}"]), i
+
+
+def test_g12_pulse_analysis_matches_the_reference():
+    """DelayAnalyzer.analyze_delay / _get_pulse_indices (code/utilities/utilities.py:343-406, :466-610) restated in
+    feeder.find_pulses / analyze_delay: same pulse indices (incl. re-inserted and re-timed pulses), same metadata,
+    same cubic-interpolated trajectory as the reference's own methods (golden g12)."""
+    from ntm_amd.feeder import analyze_delay
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g12_delay_analysis.npz"))
+    fs = int(g["fs"])
+    for i in range(int(g["n"])):
+        xi, yi, T, xm, ym = analyze_delay(g[f"in{i}"].astype(np.float64), g[f"out{i}"].astype(np.float64), fs)
+        assert np.array_equal(xi, g[f"x_idx{i}"]) and np.array_equal(yi, g[f"y_idx{i}"]), i
+        assert np.allclose([xm["reconstruction_percentage"], xm["wiggle_percentage"],
+                            ym["reconstruction_percentage"], ym["wiggle_percentage"]], g[f"meta{i}"])
+        assert T.shape == g[f"T{i}"].shape and np.abs(T - g[f"T{i}"]).max() < 1e-15, i
+
+
+def test_stereo_dataset_without_sidecars_is_analysed_and_cached(tmp_path):
+    """First use of a stereo dataset: pilots analysed, side-car written in the reference's format, statistics and
+    per-segment trajectories available; second use loads the cache and gives the same numbers."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g12_delay_analysis.npz"))
+    fs = int(g["fs"])
+    d = tmp_path / "Set" / "Val"
+    d.mkdir(parents=True)
+    rng = np.random.default_rng(1)
+    N = len(g["in0"])
+    audio = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    wavfile.write(str(d / "input_3_a.wav"), fs, np.stack([audio, g["in0"]], 1))
+    wavfile.write(str(d / "target_3_a.wav"), fs, np.stack([0.5 * audio, g["out0"]], 1))
+    f = SegmentFeeder(str(tmp_path / "Set"), subset="val", length=20000)
+    assert os.path.exists(str(d / "trajectory_3_a.npy"))
+    assert abs(f.max_delay - g["T0"].max()) < 1e-12 and abs(f.mean_delay - g["T0"].mean()) < 1e-12
+    x, t, meta = f[1]
+    assert np.allclose(meta["delay_trajectory"].numpy(), g["T0"][20000:40000], atol=1e-8)
+    f2 = SegmentFeeder(str(tmp_path / "Set"), subset="val", length=20000, analyze=False)      # from the cache
+    assert abs(f2.max_delay - f.max_delay) < 1e-15 and np.array_equal(f2[1][2]["input_peaks"], meta["input_peaks"])
