@@ -5,9 +5,9 @@ on the MI355X engine: same UPPER_CASE flags where they apply, batched over segme
     python tools/test_model.py --DATASET_DIR <dir with Test/input_*.wav, target_*.wav> \
         --WEIGHTS "GRU-HS[64]-L[DCPreESR]-DS[...]_BEST" --SEGMENT_LENGTH 441000 --BATCH_SIZE 64 --COMPUTE_LOSS
 
-Differences: plotting / WAV export / noise are out of scope; DiffDelGRU, `--DEMODULATE` and the dataset-derived
-INIT_LEN need the `trajectory_<id>_*.npy` side-cars DelayAnalyzer caches (its pulse analysis is not built; without
-side-cars give `--MAX_DELAY` in seconds);
+Differences: plotting / WAV export / noise are out of scope; delay trajectories (DiffDelGRU, `--DEMODULATE`, the
+dataset-derived INIT_LEN) come from the `trajectory_<id>_*.npy` side-cars, which the feeder computes and caches on
+first use for stereo datasets exactly as DelayAnalyzer does; mono datasets give `--MAX_DELAY` in seconds;
 `--WEIGHTS` names one of the exported checkpoints (ntm_amd.weights.available()) or a directory with best.pth.
 """
 import argparse
