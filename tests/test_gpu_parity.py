@@ -679,3 +679,37 @@ def test_random_shapes_all_exact_kernels_agree_with_oracle(ntm):
             y = m(dev(x).unsqueeze(1)).cpu().numpy()[:, 0]
             assert np.abs(y - yo).max() < TOL, (variant, B, T)
             assert np.abs(m.hidden.cpu().numpy()[0] - ho).max() < TOL, (variant, B, T)
+
+
+def test_cli_diffdel_on_raw_stereo_dataset(ntm, tmp_path):
+    """The whole evaluation path for DiffDelGRU from a RAW stereo dataset (audio + pilot pulses, no side-cars):
+    pulse analysis -> side-car -> INIT_LEN and delay-line length from the dataset's max delay
+    (code/test-model.py:223,323-324) -> batched predict with the per-sample trajectory -> losses, against the oracle."""
+    import importlib.util
+    from scipy.io import wavfile
+    spec = importlib.util.spec_from_file_location("ntm_cli2", os.path.join(os.path.dirname(os.path.dirname(__file__)),
+                                                                           "tools", "test_model.py"))
+    cli = importlib.util.module_from_spec(spec); spec.loader.exec_module(cli)
+    g = load("g12_delay_analysis.npz")
+    fs, N = int(g["fs"]), len(g["in0"])
+    d = tmp_path / "Wow" / "Test"
+    d.mkdir(parents=True)
+    rng = np.random.default_rng(21)
+    audio = rng.uniform(-0.4, 0.4, N).astype(np.float32)
+    tgt_audio = (0.3 * np.roll(audio, 1200) + 0.01 * rng.standard_normal(N)).astype(np.float32)
+    wavfile.write(str(d / "input_0_.wav"), fs, np.stack([audio, g["in0"]], 1))
+    wavfile.write(str(d / "target_0_.wav"), fs, np.stack([tgt_audio, g["out0"]], 1))
+    L = 11000
+    got = cli.main(["--DATASET_DIR", str(tmp_path / "Wow"), "--WEIGHTS", W_D, "--SEGMENT_LENGTH", str(L), "--COMPUTE_LOSS"])
+    # expected, from the reference's own analysis result (golden g12) and the oracle
+    T = g["T0"]
+    max_delay_n = int(1.25 * T.max() * fs)
+    init = 1 << (int(T.max() * fs) - 1).bit_length()
+    wd = oracle_weights(W_D)
+    nseg = N // L
+    X = np.stack([audio[k * L:(k + 1) * L] for k in range(nseg)])
+    D = np.stack([(T[k * L:(k + 1) * L]).astype(np.float32) * np.float32(fs) for k in range(nseg)])
+    yo, _, _, _ = oracle.diffdel_predict(wd, X, D, max_delay_n)
+    Tg = np.stack([tgt_audio[k * L:(k + 1) * L] for k in range(nseg)])
+    want = float(np.mean(oracle.esr_per_segment(yo, Tg, init)))
+    assert init == 2048 and abs(got["ESR"] - want) < 1e-3 * want, (got, want)
