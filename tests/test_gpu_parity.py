@@ -713,3 +713,37 @@ def test_cli_diffdel_on_raw_stereo_dataset(ntm, tmp_path):
     Tg = np.stack([tgt_audio[k * L:(k + 1) * L] for k in range(nseg)])
     want = float(np.mean(oracle.esr_per_segment(yo, Tg, init)))
     assert init == 2048 and abs(got["ESR"] - want) < 1e-3 * want, (got, want)
+
+
+def test_cli_add_delay_mode(ntm, tmp_path):
+    """`--ADD_DELAY` with a GRU model (code/test-model.py:236-240, 355-364; the reference's own helper raises
+    TypeError): the measured trajectory is applied to the model output before the loss."""
+    import importlib.util
+    from scipy.io import wavfile
+    spec = importlib.util.spec_from_file_location("ntm_cli3", os.path.join(os.path.dirname(os.path.dirname(__file__)),
+                                                                           "tools", "test_model.py"))
+    cli = importlib.util.module_from_spec(spec); spec.loader.exec_module(cli)
+    g = load("g12_delay_analysis.npz")
+    fs, N = int(g["fs"]), len(g["in1"])
+    d = tmp_path / "Wow" / "Test"
+    d.mkdir(parents=True)
+    rng = np.random.default_rng(4)
+    audio = rng.uniform(-0.4, 0.4, N).astype(np.float32)
+    tgt_audio = (0.2 * np.roll(audio, 1200)).astype(np.float32)
+    wavfile.write(str(d / "input_0_.wav"), fs, np.stack([audio, g["in1"]], 1))
+    wavfile.write(str(d / "target_0_.wav"), fs, np.stack([tgt_audio, g["out1"]], 1))
+    L = 14000
+    got = cli.main(["--DATASET_DIR", str(tmp_path / "Wow"), "--WEIGHTS", W_G, "--SEGMENT_LENGTH", str(L), "--COMPUTE_LOSS",
+                    "--ADD_DELAY"])
+    T = g["T1"]
+    D = int(1.25 * T.max() * fs)
+    init = 1 << (int(T.max() * fs) - 1).bit_length()
+    w = oracle_weights(W_G)
+    nseg = N // L
+    X = np.stack([audio[k * L:(k + 1) * L] for k in range(nseg)])
+    Dt = np.stack([(T[k * L:(k + 1) * L]).astype(np.float32) * np.float32(fs) for k in range(nseg)])
+    yo, _ = oracle.gru_predict(w, X)
+    yd, _ = oracle.delay_forward(yo, Dt, np.zeros((nseg, D), np.float32))
+    Tg = np.stack([tgt_audio[k * L:(k + 1) * L] for k in range(nseg)])
+    want = float(np.mean(oracle.esr_per_segment(yd, Tg, init)))
+    assert abs(got["ESR"] - want) < 1e-3 * want, (got, want)

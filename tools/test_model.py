@@ -35,6 +35,8 @@ def main(argv=None):
     p.add_argument('--MAX_DELAY', type=float, default=0.0, help="seconds (DelayAnalyzer.max_delay of the dataset)")
     p.add_argument('--COMPUTE_LOSS', action='store_true', default=False)
     p.add_argument('--DEMODULATE', action='store_true', default=False)
+    p.add_argument('--ADD_DELAY', action='store_true', default=False,
+                   help="GRU only: apply the measured delay trajectory to the model output (code/test-model.py:236-240,355-364)")
     p.add_argument('--KERNEL', type=str, default="auto")
     a = p.parse_args(argv)
 
@@ -57,22 +59,28 @@ def main(argv=None):
     per = {"ESR": [], "DCPreESR": [], "MultiSTFT": []}
     mrstft = ntm_amd.MRSTFTLoss()
     def batches():
-        if is_dd or a.DEMODULATE or a.STREAM_CHUNK <= 0:
+        if is_dd or a.DEMODULATE or a.ADD_DELAY or a.STREAM_CHUNK <= 0:
             for xin, tgt, dt, _ in feeder.batches(a.BATCH_SIZE, "cuda", rank, world):
                 if is_dd:
                     assert dt is not None, "DiffDelGRU needs trajectory_<id>_*.npy side-cars"
                     out, _ = model.predict(xin, dt * feeder.fs)
                 else:
                     out = model.predict(xin)
-                yield xin, tgt, out
+                yield xin, tgt, out, dt
         else:
             # GRU: predict straight from the feeder's pinned files, H2D copies pipelined along time under the launches
             lo, hi = D.shard_range(len(feeder), rank, world)
             for b0 in range(lo, hi, a.BATCH_SIZE):
                 out, xin, tgt = feeder.predict_streamed(model, b0, min(hi, b0 + a.BATCH_SIZE), chunk=a.STREAM_CHUNK)
-                yield xin, tgt, out
+                yield xin, tgt, out, None
 
-    for xin, tgt, out in batches():
+    delay = None
+    if a.ADD_DELAY and not is_dd:
+        assert feeder.max_delay > 0, "--ADD_DELAY needs delay trajectories (stereo dataset or side-cars)"
+        delay = ntm_amd.TimeVaryingDelayLine(max_delay=int(1.25 * feeder.max_delay * feeder.fs))      # code/test-model.py:237-238
+    for xin, tgt, out, dt in batches():
+        if delay is not None:
+            out = ntm_amd.harness.apply_delay(delay, dt * feeder.fs, out)
         n = xin.shape[-1] - init_len
         for key, fn in (("ESR", esr_sums), ("DCPreESR", esr_dcpre_sums)):
             s = fn(out, tgt, skip=init_len)
