@@ -747,3 +747,23 @@ def test_cli_add_delay_mode(ntm, tmp_path):
     Tg = np.stack([tgt_audio[k * L:(k + 1) * L] for k in range(nseg)])
     want = float(np.mean(oracle.esr_per_segment(yd, Tg, init)))
     assert abs(got["ESR"] - want) < 1e-3 * want, (got, want)
+
+
+@pytest.mark.parametrize("B,D,chunks", [(3, 8900, (2048, 2048, 2048, 857)), (2, 1, (5, 1, 7)), (4, 37, (10, 37, 36, 38, 100)),
+                                        (1, 8900, (12000,)), (130, 300, (299, 301))])
+def test_delay_line_sizes_and_chunking_bit_exact(ntm, B, D, chunks):
+    """Delay line at the real-data buffer length (D = 8900), degenerate D = 1, chunks shorter / equal / longer than
+    the buffer, state carried: bit-exact against the oracle (itself bit-exact against the reference, golden g4)."""
+    rng = np.random.default_rng(D + B)
+    dl = ntm.TimeVaryingDelayLine(max_delay=D)
+    dl.init_buffer(B, D)
+    buf = np.zeros((B, D), np.float32)
+    for T in chunks:
+        x = rng.standard_normal((B, T)).astype(np.float32)
+        d = rng.uniform(0, D, (B, T)).astype(np.float32)
+        d[:, ::7] = np.floor(d[:, ::7])                       # integer delays
+        d[0, :min(T, 3)] = [D, 0.0, D - 0.25][:min(T, 3)]      # the bounds
+        yo, buf = oracle.delay_forward(x, d, buf)
+        y = dl(dev(x).unsqueeze(1), dev(d).unsqueeze(1)).cpu().numpy()[:, 0, :]
+        assert np.array_equal(y, yo), (D, T)
+        assert np.array_equal(dl.buffer.cpu().numpy()[:, 0, :], buf), (D, T)
