@@ -505,8 +505,7 @@ hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream)
     constexpr size_t smem4 = m2::smem_floats(4) * sizeof(float);     //  53 376 B: up to three per CU
     static_assert(smem16 <= 160 * 1024, "LDS carve-up");
     const unsigned grid = (unsigned)((a.B + m2::SG - 1) / m2::SG);
-    const char *force = getenv("NTM_FORCE_PLANES");                 // test hook: "4" or "16"
-    const bool many = force ? (force[0] == '4') : grid >= 512;       // >= 2 stream groups per CU
+    const bool many = grid >= 512;                                   // >= 2 stream groups per CU
 #define NTM2_ABL_CASE(M) case M: return launch_m2(gru_mfma2_kernel<true, false, M>, smem16, grid, a, stream);
     switch (a.abl) {
         NTM2_ABL_CASE(1) NTM2_ABL_CASE(2) NTM2_ABL_CASE(4) NTM2_ABL_CASE(8) NTM2_ABL_CASE(16) NTM2_ABL_CASE(32)
