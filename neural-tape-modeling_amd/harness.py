@@ -72,3 +72,65 @@ def apply_delay(delay, delay_trajectory, output, segment_length=None):
         sl = slice(i * segment_length, (i + 1) * segment_length)
         out[:, :, sl] = delay(output[:, :, sl], delay_trajectory[:, :, sl])
     return out
+
+
+class BlockStreamer:
+    """Block-by-block (real-time style) inference: B streams advance `block` samples per call with the GRU state kept
+    on the device in preallocated buffers; one ctypes call per block on the low-latency kernel.  Measured on the
+    MI355X (tools/block_latency_probe.py): 31 us per 64-sample block of one stream (26 us of it kernel; the block
+    lasts 1451 us at 44.1 kHz), 58 us for 16 streams x 128 samples, 219 us for 256 x 512 -- i.e. about 5 us of
+    launch overhead.  Capturing the launch in a HIP graph and replaying it (`use_graph=True`, torch.cuda.CUDAGraph)
+    was measured too and is SLOWER by 8 us per block: with a single kernel per block there is nothing for a graph to
+    amortise, so it is off by default.  Same numbers as model.forward() on the concatenated blocks either way.
+
+        s = BlockStreamer(model, B=16, block=128)          # RNN only; warm-start included unless warm=False
+        y = s.process(x_block)                             # (B,1,block) in -> (B,1,block) view, valid until the next call
+    """
+
+    def __init__(self, model, B, block, warm=True, use_graph=False):
+        from . import _lib
+        from ._lib import ptr
+        if not isinstance(model, RNN):
+            raise TypeError("BlockStreamer drives the GRU model (RNN)")
+        dev = model.GRU.weight_hh_l0.device
+        self.model, self.B, self.block = model, B, block
+        self.x = torch.zeros(B, 1, block, device=dev, dtype=torch.float32)
+        self.y = torch.empty(B, 1, block, device=dev, dtype=torch.float32)
+        if warm:
+            model.initialize_hidden()
+            model.warm_start()
+            self.h = model.hidden.expand(1, B, model.hidden_size).contiguous().clone()
+        else:
+            self.h = torch.zeros(1, B, model.hidden_size, device=dev, dtype=torch.float32)
+        g, o = model.GRU, model.output
+        lib, variant = _lib.lib(), _lib.VARIANTS[model.kernel_variant]
+
+        def launch():
+            rc = lib.ntm_gru_forward_ex(ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0),
+                                        ptr(o.weight), ptr(o.bias), model.hidden_size, ptr(self.x), ptr(self.y), B, block,
+                                        block, block, ptr(self.h), variant, _lib.current_stream())
+            _lib.check(rc, "ntm_gru_forward")
+
+        self._launch = launch
+        self.graph = None
+        if use_graph:
+            h0 = self.h.clone()
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                launch()                                    # warm the code path outside the capture
+            torch.cuda.current_stream().wait_stream(side)
+            self.h.copy_(h0)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                launch()
+            self.h.copy_(h0)                                # capture does not execute, but keep the state explicit
+
+    @torch.no_grad()
+    def process(self, x_block):
+        self.x.copy_(x_block.reshape(self.B, 1, self.block), non_blocking=True)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._launch()
+        return self.y

@@ -767,3 +767,16 @@ def test_delay_line_sizes_and_chunking_bit_exact(ntm, B, D, chunks):
         y = dl(dev(x).unsqueeze(1), dev(d).unsqueeze(1)).cpu().numpy()[:, 0, :]
         assert np.array_equal(y, yo), (D, T)
         assert np.array_equal(dl.buffer.cpu().numpy()[:, 0, :], buf), (D, T)
+
+
+@pytest.mark.parametrize("B,block,use_graph", [(16, 128, True), (3, 64, True), (1, 512, False)])
+def test_block_streamer_graph_replay(ntm, B, block, use_graph):
+    """Real-time style blocks through a captured HIP graph == predict() on the concatenated signal."""
+    rng = np.random.default_rng(B + block)
+    nblk = 9
+    x = rng.uniform(-0.5, 0.5, (B, nblk * block)).astype(np.float32)
+    m = make_rnn(ntm, W_G, "auto")
+    want = m.predict(dev(x).unsqueeze(1))
+    s = ntm.harness.BlockStreamer(m, B, block, use_graph=use_graph)
+    got = torch.cat([s.process(dev(x[:, k * block:(k + 1) * block]).unsqueeze(1)).clone() for k in range(nblk)], 2)
+    assert torch.equal(got, want)
