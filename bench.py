@@ -189,42 +189,56 @@ def main():
     INIT_LEN = 1024
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    kern_ms = []
+    side = torch.cuda.Stream(device=dev)       # the loss leg (ESR sums + the job-wide reduction) runs here
 
-    def one_pass(target):
-        # == model.predict(x) (code/model.py:218-246), unrolled so the events bracket the main launch
+    def one_pass(target, evs=(ev0, ev1)):
+        """One step: model.predict(x) (code/model.py:218-246, unrolled so the events bracket the main launch) and,
+        when a target is given, the ESR sums + reduction of code/test-model.py:386-398 on the side stream -- the
+        next step's launches do not wait for them (the K timed steps are bracketed by synchronisation on both
+        sides; inside, the HBM-bound loss leg of step k overlaps the compute-bound GRU launch of step k+1).
+        -> (y, pending loss reduction or None)"""
         model.initialize_hidden()
         model.warm_start()
         model.hidden = model.hidden.expand(1, B, 64).contiguous()
-        ev0.record()
+        evs[0].record()
         y = model.forward(x)
-        ev1.record()
-        res = None
+        evs[1].record()
+        pend = None
         if target is not None:
-            s = esr_sums(y, target, skip=INIT_LEN)
-            n = T - INIT_LEN
-            res = D.reduce_loss_sums((s[:, 0] / n) / (s[:, 1] / n + ESR_EPS), s)
-        return y, res
+            side.wait_event(evs[1])
+            y.record_stream(side)
+            with torch.cuda.stream(side):
+                s = esr_sums(y, target, skip=INIT_LEN)
+                n = T - INIT_LEN
+                pend = D.reduce_loss_sums_begin((s[:, 0] / n) / (s[:, 1] / n + ESR_EPS), s)
+        return y, pend
 
     target = None
     for _ in range(max(a.warmup, 0)):
-        y, _ = one_pass(target)
+        y, pend = one_pass(target)
+        if pend is not None:
+            D.reduce_loss_sums_end(pend)
         if target is None:
             target = y.clone()
     if target is None:                      # --warmup 0: still need the determinism target
         target = one_pass(None)[0].clone()
 
+    step_evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     D.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res = None
-    for _ in range(a.steps):
-        y, res = one_pass(target)
-        torch.cuda.synchronize()
-        kern_ms.append(ev0.elapsed_time(ev1))
+    pends = []
+    for k in range(a.steps):
+        y, pend = one_pass(target, step_evs[k])
+        pends.append(pend)
+    torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
+    results = [D.reduce_loss_sums_end(p) for p in pends]
+    res = results[-1] if results else None
+    assert all(r["mean_segment_loss"] == results[0]["mean_segment_loss"] for r in results)     # every step: same numbers
+    kern_ms = [e0.elapsed_time(e1) for e0, e1 in step_evs]
 
     # ---- opt-in kernel variant, reported beside the headline (never part of `value`): the f16x3 GEMV
     #      engine, checked over the whole batch against the exact-fp32 pass
@@ -306,7 +320,7 @@ def main():
         "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": f"GRU-HS[64] CHOWTAPE weights, {B} segments x {T} samples fp32 per GPU, "
-                               f"predict (warm-start + persistent GRU kernel) + ESR sums + all-reduce",
+                               f"predict (warm-start + persistent GRU kernel) + ESR sums + all-reduce on a side stream, overlapping the next step's launch",
                    "segments_per_gpu": B, "samples_per_segment": T, "kernel": a.variant,
                    "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
         "realtime_factor": total_samples / elapsed / FS,

@@ -54,6 +54,34 @@ def reduce_loss_sums(per_segment_loss, err_sums=None, group=None):
             "sum_err2": float(v[2]), "sum_tgt2": float(v[3])}
 
 
+def reduce_loss_sums_begin(per_segment_loss, err_sums=None, group=None):
+    """First half of reduce_loss_sums: builds the 4 fp64 scalars and issues the SUM all-reduce on the CURRENT
+    stream without fetching the result -- the caller keeps launching work and calls reduce_loss_sums_end later."""
+    dev = per_segment_loss.device
+    parts = [per_segment_loss.double().sum().reshape(1),
+             torch.full((1,), float(per_segment_loss.numel()), dtype=torch.float64, device=dev),
+             err_sums.double().sum(dim=0) if err_sums is not None else torch.zeros(2, dtype=torch.float64, device=dev)]
+    v = torch.cat(parts)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+    ev = None
+    if v.is_cuda:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(v.device))
+    return v, ev
+
+
+def reduce_loss_sums_end(pending):
+    """Second half: wait for the stream that produced the reduced scalars, then fetch them."""
+    v, ev = pending
+    if ev is not None:
+        ev.synchronize()
+    v = v.cpu()
+    n = int(v[1].item())
+    return {"mean_segment_loss": float(v[0] / max(n, 1)), "segments": n,
+            "sum_err2": float(v[2]), "sum_tgt2": float(v[3])}
+
+
 def max_over_ranks(value, device):
     """MAX all-reduce of one python float (used for the benchmark's elapsed time)."""
     t = torch.tensor([value], dtype=torch.float64, device=device)

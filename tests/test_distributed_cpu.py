@@ -64,3 +64,14 @@ def test_two_rank_loss_reduction_matches_single_process():
         assert abs(res["sum_err2"] - sums[0]) < 1e-9 * sums[0]
         assert abs(res["sum_tgt2"] - sums[1]) < 1e-9 * sums[1]
         assert tmax == 2.0
+
+
+def test_reduce_loss_sums_two_phase_single_process():
+    """begin/end pair (used by bench.py to keep the loss leg off the launch path) == the one-call form."""
+    import torch
+    from ntm_amd import distributed as D
+    per = torch.tensor([0.1, 0.2, 0.4], dtype=torch.float64)
+    sums = torch.tensor([[1.0, 2.0], [3.0, 4.0], [5.0, 6.0]], dtype=torch.float64)
+    a = D.reduce_loss_sums(per, sums)
+    b = D.reduce_loss_sums_end(D.reduce_loss_sums_begin(per, sums))
+    assert a == b and abs(a["mean_segment_loss"] - 0.7 / 3) < 1e-15 and a["sum_err2"] == 9.0 and a["sum_tgt2"] == 12.0
