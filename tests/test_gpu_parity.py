@@ -780,3 +780,29 @@ def test_block_streamer_graph_replay(ntm, B, block, use_graph):
     s = ntm.harness.BlockStreamer(m, B, block, use_graph=use_graph)
     got = torch.cat([s.process(dev(x[:, k * block:(k + 1) * block]).unsqueeze(1)).clone() for k in range(nblk)], 2)
     assert torch.equal(got, want)
+
+
+def test_c_abi_from_a_plain_cpp_process(ntm, tmp_path):
+    """The boundary really is a C ABI: tools/cabi/cabi_demo (C++, raw HIP allocations, no torch, no Python) calls
+    ntm_gru_forward on the raw weight file and gets the numbers of the Python layer / the oracle."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(__file__))
+    exe = os.path.join(root, "tools", "cabi", "cabi_demo.bin")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.dirname(exe)], check=True)
+    rng = np.random.default_rng(8)
+    B, T = 19, 700
+    x = rng.uniform(-0.5, 0.5, (B, T)).astype(np.float32)
+    x.tofile(str(tmp_path / "x.f32"))
+    wfile = os.path.join(root, "neural-tape-modeling_amd", "weights", "w0.bin")
+    r = subprocess.run([exe, wfile, str(tmp_path / "x.f32"), str(B), str(T), str(tmp_path / "y.f32"), str(tmp_path / "h.f32")],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "only hidden size 64" in r.stdout                       # the refusal message of the error-path call
+    y = np.fromfile(str(tmp_path / "y.f32"), np.float32).reshape(B, T)
+    h = np.fromfile(str(tmp_path / "h.f32"), np.float32).reshape(B, 64)
+    yo, ho = oracle.gru_forward(oracle_weights(W_G), x)
+    assert np.abs(y - yo).max() < TOL and np.abs(h - ho).max() < TOL
+    m = make_rnn(ntm, W_G, "auto")
+    m.initialize_hidden()
+    assert np.array_equal(m(dev(x).unsqueeze(1)).cpu().numpy()[:, 0], y)      # same kernel, same bits

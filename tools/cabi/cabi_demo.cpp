@@ -1,0 +1,55 @@
+// Stand-alone caller of the C ABI (include/ntm.h) with NO torch and NO Python in the process: raw HIP
+// allocations, raw weight file, one ntm_gru_forward call, result written as raw fp32 for the test to compare.
+//   usage: cabi_demo <w0.bin> <x.f32> <B> <T> <y_out.f32> <h_out.f32>
+// w0.bin layout (neural-tape-modeling_amd/weights/manifest.json): W_ih[192] W_hh[192*64] b_ih[192] b_hh[192]
+// W_o[64] b_o[1], little-endian fp32 -- the reference's state_dict order (code/model.py:44-45).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "ntm.h"
+
+static std::vector<float> read_f32(const char *path, size_t want)
+{
+    std::vector<float> v(want);
+    FILE *f = fopen(path, "rb");
+    if (!f || fread(v.data(), sizeof(float), want, f) != want) { fprintf(stderr, "cannot read %zu floats from %s\n", want, path); exit(2); }
+    fclose(f);
+    return v;
+}
+
+#define HIP_OK(e) do { hipError_t _e = (e); if (_e != hipSuccess) { fprintf(stderr, "%s: %s\n", #e, hipGetErrorString(_e)); return 3; } } while (0)
+
+int main(int argc, char **argv)
+{
+    if (argc != 7) { fprintf(stderr, "usage: %s w0.bin x.f32 B T y_out.f32 h_out.f32\n", argv[0]); return 1; }
+    const long B = atol(argv[3]), T = atol(argv[4]);
+    const size_t nw = 192 + 192 * 64 + 192 + 192 + 64 + 1;
+    std::vector<float> w = read_f32(argv[1], nw), x = read_f32(argv[2], (size_t)B * T);
+    float *dw, *dx, *dy, *dh;
+    HIP_OK(hipMalloc(&dw, nw * sizeof(float)));
+    HIP_OK(hipMalloc(&dx, x.size() * sizeof(float)));
+    HIP_OK(hipMalloc(&dy, x.size() * sizeof(float)));
+    HIP_OK(hipMalloc(&dh, (size_t)B * 64 * sizeof(float)));
+    HIP_OK(hipMemcpy(dw, w.data(), nw * sizeof(float), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dx, x.data(), x.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(dh, 0, (size_t)B * 64 * sizeof(float)));
+    hipStream_t stream;
+    HIP_OK(hipStreamCreate(&stream));
+    const float *w_ih = dw, *w_hh = dw + 192, *b_ih = w_hh + 192 * 64, *b_hh = b_ih + 192, *w_o = b_hh + 192, *b_o = w_o + 64;
+    if (ntm_abi_version() != 1) { fprintf(stderr, "unexpected ABI version\n"); return 4; }
+    int rc = ntm_gru_forward(w_ih, w_hh, b_ih, b_hh, w_o, b_o, NTM_HIDDEN, dx, dy, B, T, T, T, dh, stream);
+    if (rc != NTM_OK) { fprintf(stderr, "ntm_gru_forward: %d %s\n", rc, ntm_last_error()); return 5; }
+    // error path: wrong hidden size must be refused with a message, not crash
+    if (ntm_gru_forward(w_ih, w_hh, b_ih, b_hh, w_o, b_o, 32, dx, dy, B, T, T, T, dh, stream) == NTM_OK) return 6;
+    HIP_OK(hipStreamSynchronize(stream));
+    std::vector<float> y(x.size()), h((size_t)B * 64);
+    HIP_OK(hipMemcpy(y.data(), dy, y.size() * sizeof(float), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(h.data(), dh, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+    FILE *f = fopen(argv[5], "wb"); fwrite(y.data(), sizeof(float), y.size(), f); fclose(f);
+    f = fopen(argv[6], "wb"); fwrite(h.data(), sizeof(float), h.size(), f); fclose(f);
+    printf("ok B=%ld T=%ld last_error_after_refusal=\"%s\"\n", B, T, ntm_last_error());
+    return 0;
+}
