@@ -147,12 +147,22 @@ int ntm_esr_dcpre_sums(const float *y, const float *t, int64_t B, int64_t T, int
  * mag = sqrt(max(re^2 + im^2, power_eps)), and with P = 4 * chunks partial rows per stream
  *   out[(b*P + p)*4 + 0..3] = sum (mag_t - mag_y)^2 | sum mag_t^2 | sum |ln mag_y - ln mag_t| | sum |mag_y - mag_t|
  * (fp64, device; the caller adds the P rows of a stream).  y = prediction, t = target, [B,T] contiguous.
- * n_fft in {256, 512, 1024, 2048}; 0 < win_length <= n_fft; T - skip > n_fft/2; power_eps > 0 (auraloss: 1e-8);
+ * n_fft in {64, 128, 256, 512, 1024, 2048}; 0 < win_length <= n_fft; T - skip > n_fft/2; power_eps > 0 (auraloss: 1e-8);
  * chunks >= 1 splits the frames of a stream over that many workgroups.  There are 1 + (T-skip)/hop frames
  * of n_fft/2 + 1 bins.
  */
 int ntm_stft_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int n_fft, int hop,
                   int win_length, float power_eps, int chunks, double *out, void *stream);
+
+/*
+ * Same transform and layout as ntm_stft_sums, with the POWER-spectrogram terms of the reference's validation
+ * metric bundle (code/evaluation.py:75-84: `TimeFreqConverter` = torchaudio Spectrogram(n_fft, hop = n_fft/4,
+ * power = 2), un-vendored torchaudio semantics = torch.stft, parity pinned to torch.stft by golden g13):
+ *   out[..0..3] = sum |P_y - P_t| | sum |log10 max(P_y, log_floor) - log10 max(P_t, log_floor)| | sum P_t | sum P_y
+ * (log_floor = 1e-5 in the reference).
+ */
+int ntm_spec_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int n_fft, int hop,
+                  int win_length, float log_floor, int chunks, double *out, void *stream);
 
 /*
  * "Next" row N2 plumbing: pitched asynchronous copy between (pinned) host memory and the device, rows x

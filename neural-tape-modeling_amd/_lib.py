@@ -32,6 +32,7 @@ _SIGNATURES = {
                                                    _vp, _vp, _vp]),
     "ntm_esr_sums": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "ntm_esr_dcpre_sums": (_int, [_vp, _vp, _i64, _i64, _i64, ctypes.c_float, _vp, _vp]),
+    "ntm_spec_sums": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _int, _int, ctypes.c_float, _int, _vp, _vp]),
     "ntm_stft_sums": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _int, _int, ctypes.c_float, _int, _vp, _vp]),
     "ntm_copy2d_async": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _int, _vp]),
     "ntm_demodulate": (_int, [_vp, _vp, _int, _i64, _vp, _int, _i64, _i64, _vp, _vp]),

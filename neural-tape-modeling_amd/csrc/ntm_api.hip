@@ -14,7 +14,7 @@ hipError_t launch_esr(const float *y, const float *t, int64_t B, int64_t T, int6
 hipError_t launch_esr_dcpre(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, float R, double *out,
                             hipStream_t stream);
 hipError_t launch_stft_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int n_fft, int hop,
-                            int win, float eps, int chunks, double *out, hipStream_t stream);
+                            int win, float eps, int chunks, int mode, double *out, hipStream_t stream);
 hipError_t launch_demodulate(const float *x, float *out, int C, int64_t N, const int64_t *y_idx, int P, int64_t period,
                              int64_t shift, double *scratch, hipStream_t stream);
 hipError_t launch_tape_hmag(const double *H, double *M, int64_t B, int64_t N, double *state, double Ts, const double *par,
@@ -154,21 +154,34 @@ int ntm_esr_dcpre_sums(const float *y, const float *t, int64_t B, int64_t T, int
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_esr_dcpre_sums");
 }
 
+static int stft_common(const char *who, const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int n_fft, int hop,
+                       int win_length, float floor_, int chunks, int mode, double *out, void *stream)
+{
+    const std::string w(who);
+    if (B < 0 || T < 0 || skip < 0 || skip > T) return fail(NTM_EINVAL, w + ": bad size");
+    if (n_fft != 64 && n_fft != 128 && n_fft != 256 && n_fft != 512 && n_fft != 1024 && n_fft != 2048)
+        return fail(NTM_EINVAL, w + ": n_fft must be a power of two from 64 to 2048");
+    if (hop <= 0 || win_length <= 0 || win_length > n_fft) return fail(NTM_EINVAL, w + ": bad hop or win_length");
+    if (!(floor_ > 0.0f)) return fail(NTM_EINVAL, w + ": the power floor must be positive");
+    if (chunks < 1 || B * (int64_t)chunks > 0x7fffffff) return fail(NTM_EINVAL, w + ": bad chunks");
+    if (B == 0) return NTM_OK;
+    if (T - skip <= n_fft / 2) return fail(NTM_EINVAL, w + ": reflect padding needs T - skip > n_fft/2");
+    if (T - skip > 0x7fffffff - 4096) return fail(NTM_EINVAL, w + ": T - skip must be below 2^31 - 4096");
+    if (!y || !t || !out) return fail(NTM_EINVAL, w + ": null pointer");
+    hipError_t e = ntm::launch_stft_sums(y, t, B, T, skip, n_fft, hop, win_length, floor_, chunks, mode, out, (hipStream_t)stream);
+    return e == hipSuccess ? NTM_OK : hip_fail(e, who);
+}
+
 int ntm_stft_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int n_fft, int hop, int win_length,
                   float power_eps, int chunks, double *out, void *stream)
 {
-    if (B < 0 || T < 0 || skip < 0 || skip > T) return fail(NTM_EINVAL, "ntm_stft_sums: bad size");
-    if (n_fft != 256 && n_fft != 512 && n_fft != 1024 && n_fft != 2048)
-        return fail(NTM_EINVAL, "ntm_stft_sums: n_fft must be 256, 512, 1024 or 2048");
-    if (hop <= 0 || win_length <= 0 || win_length > n_fft) return fail(NTM_EINVAL, "ntm_stft_sums: bad hop or win_length");
-    if (!(power_eps > 0.0f)) return fail(NTM_EINVAL, "ntm_stft_sums: power_eps must be positive");
-    if (chunks < 1 || B * (int64_t)chunks > 0x7fffffff) return fail(NTM_EINVAL, "ntm_stft_sums: bad chunks");
-    if (B == 0) return NTM_OK;
-    if (T - skip <= n_fft / 2) return fail(NTM_EINVAL, "ntm_stft_sums: reflect padding needs T - skip > n_fft/2");
-    if (T - skip > 0x7fffffff - 4096) return fail(NTM_EINVAL, "ntm_stft_sums: T - skip must be below 2^31 - 4096");
-    if (!y || !t || !out) return fail(NTM_EINVAL, "ntm_stft_sums: null pointer");
-    hipError_t e = ntm::launch_stft_sums(y, t, B, T, skip, n_fft, hop, win_length, power_eps, chunks, out, (hipStream_t)stream);
-    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_stft_sums");
+    return stft_common("ntm_stft_sums", y, t, B, T, skip, n_fft, hop, win_length, power_eps, chunks, 0, out, stream);
+}
+
+int ntm_spec_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int n_fft, int hop, int win_length,
+                  float log_floor, int chunks, double *out, void *stream)
+{
+    return stft_common("ntm_spec_sums", y, t, B, T, skip, n_fft, hop, win_length, log_floor, chunks, 1, out, stream);
 }
 
 int ntm_copy2d_async(void *dst, int64_t dst_pitch_bytes, const void *src, int64_t src_pitch_bytes, int64_t width_bytes,

@@ -27,7 +27,7 @@ namespace ntm {
 struct StftArgs {
     const float *y, *t;
     int64_t B, T, skip;
-    int hop, win, chunks, frames_per_chunk, n_frames;
+    int hop, win, chunks, frames_per_chunk, n_frames, mode;
     float eps;
     double *out;
 };
@@ -100,20 +100,31 @@ template <> __device__ __forceinline__ void dft<16>(f2 (&x)[16])
 // exchange-buffer index: one float2 of padding per 16 keeps the strided Stockham stores conflict-free
 __device__ __forceinline__ constexpr int padi(int i) { return i + (i >> 4); }
 
+// Frames of n_fft >= 256 use all 64 lanes of a wave (n_fft/64 points per lane); smaller frames use SUB = n_fft/4
+// lanes each (4 points per lane) and a wave transforms 64/SUB frames side by side.
+template <int N> struct Geo {
+    static constexpr int SUB = N >= 256 ? 64 : N / 4;     // lanes per frame
+    static constexpr int P = N / SUB;                     // points per lane
+    static constexpr int FPW = 64 / SUB;                  // frames per wave and iteration
+    static constexpr int NPAD = N + N / 16;               // padded exchange buffer of one frame (float2)
+};
+
 // Per-lane twiddles of one Stockham pass, radix R with sub-transform size Ns: butterfly b of this lane is
-// j = lane + 64 b, k = j mod Ns, and input t is multiplied by exp(-2 pi i t k / (Ns R)).  Frame-invariant.
+// j = sl + SUB b (sl = lane within the frame), k = j mod Ns, and input t is multiplied by
+// exp(-2 pi i t k / (Ns R)).  Frame-invariant.
 template <int N, int R, int Ns> struct PassTw {
-    static constexpr int NB = N / R / 64;
-    static constexpr int NBW = Ns <= 64 ? 1 : NB;      // Ns <= 64: k = lane mod Ns is the same for every butterfly of the lane
+    static constexpr int SUB = Geo<N>::SUB;
+    static constexpr int NB = N / R / SUB;
+    static constexpr int NBW = Ns <= SUB ? 1 : NB;     // Ns <= SUB: k = sl mod Ns is the same for every butterfly of the lane
     f2 w[Ns > 1 ? NBW * (R - 1) : 1];
-    __device__ __forceinline__ void init(int lane)
+    __device__ __forceinline__ void init(int sl)
     {
         if constexpr (Ns > 1) {
 #pragma unroll
             for (int b = 0; b < NBW; ++b)
 #pragma unroll
                 for (int t = 1; t < R; ++t) {
-                    const int k = (lane + 64 * b) & (Ns - 1);
+                    const int k = (sl + SUB * b) & (Ns - 1);
                     float sn, cs;
                     sincospif(-2.0f * (float)(t * k) / (float)(Ns * R), &sn, &cs);
                     w[b * (R - 1) + t - 1] = (f2){cs, sn};
@@ -123,20 +134,21 @@ template <int N, int R, int Ns> struct PassTw {
     __device__ __forceinline__ f2 get(int b, int t) const { return w[(NBW == 1 ? 0 : b) * (R - 1) + t - 1]; }
 };
 
-// One Stockham pass over the wave's N points: v[q] holds point lane + 64 q.
+// One Stockham pass over a frame's N points: v[q] holds point sl + SUB q; buf is the frame's exchange buffer.
 template <int N, int R, int Ns, bool FIRST>
-__device__ __forceinline__ void stockham_pass(f2 (&v)[N / 64], f2 *buf, const PassTw<N, R, Ns> &tw, int lane)
+__device__ __forceinline__ void stockham_pass(f2 (&v)[Geo<N>::P], f2 *buf, const PassTw<N, R, Ns> &tw, int sl)
 {
-    constexpr int P = N / 64, NB = N / R / 64;
+    constexpr int SUB = Geo<N>::SUB, P = Geo<N>::P, NB = N / R / SUB;
+    static_assert(NB >= 1, "radix too large for the points a lane holds");
     if constexpr (!FIRST) {
         wave_lds_fence();
 #pragma unroll
-        for (int q = 0; q < P; ++q) v[q] = buf[padi(lane + 64 * q)];
+        for (int q = 0; q < P; ++q) v[q] = buf[padi(sl + SUB * q)];
         wave_lds_fence();
     }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        const int j = lane + 64 * b;
+        const int j = sl + SUB * b;
         const int k = j & (Ns - 1);
         f2 x[R];
 #pragma unroll
@@ -155,35 +167,40 @@ __device__ __forceinline__ void stockham_pass(f2 (&v)[N / 64], f2 *buf, const Pa
 // radix plans: 256 = 4.4.4.4, 512 = 8.8.8, 1024 = 16.4.16, 2048 = 16.8.16 (the small radix in the middle pass,
 // where every butterfly of a lane shares its twiddles: fewer twiddle registers)
 template <int LOG2N> struct Plan;
+template <> struct Plan<6> { static constexpr int R0 = 4, R1 = 4, R2 = 4, R3 = 1; };      // 16 lanes per frame
+template <> struct Plan<7> { static constexpr int R0 = 4, R1 = 4, R2 = 4, R3 = 2; };      // 32 lanes per frame
 template <> struct Plan<8> { static constexpr int R0 = 4, R1 = 4, R2 = 4, R3 = 4; };
 template <> struct Plan<9> { static constexpr int R0 = 8, R1 = 8, R2 = 8, R3 = 1; };
 template <> struct Plan<10> { static constexpr int R0 = 16, R1 = 4, R2 = 16, R3 = 1; };
 template <> struct Plan<11> { static constexpr int R0 = 16, R1 = 8, R2 = 16, R3 = 1; };
 
-template <int LOG2N>
+template <int LOG2N, int MODE>
 __global__ __launch_bounds__(256, (LOG2N <= 10 ? 2 : 1)) void stft_sums_kernel(StftArgs a)
 {
-    constexpr int N = 1 << LOG2N, P = N / 64, NPAD = N + N / 16;
+    constexpr int N = 1 << LOG2N;
+    using G = Geo<N>;
+    constexpr int SUB = G::SUB, P = G::P, FPW = G::FPW, NPAD = G::NPAD;
     using PL = Plan<LOG2N>;
     constexpr int R0 = PL::R0, R1 = PL::R1, R2 = PL::R2, R3 = PL::R3;
     static_assert(R0 * R1 * R2 * R3 == N, "radix plan");
     extern __shared__ f2 stft_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    f2 *buf = stft_smem + wave * NPAD;        // this wave's exchange buffer
+    const int sl = lane & (SUB - 1), fs = lane / SUB;          // lane within the frame, frame slot within the wave
+    f2 *buf = stft_smem + (wave * FPW + fs) * NPAD;            // this frame slot's exchange buffer
 
     PassTw<N, R1, R0> tw1;
     PassTw<N, R2, R0 * R1> tw2;
     PassTw<N, (R3 > 1 ? R3 : 2), R0 * R1 * R2 / (R3 > 1 ? 1 : 2)> tw3;      // (unused when R3 == 1)
-    tw1.init(lane);
-    tw2.init(lane);
-    if constexpr (R3 > 1) tw3.init(lane);
+    tw1.init(sl);
+    tw2.init(sl);
+    if constexpr (R3 > 1) tw3.init(sl);
 
-    // window value of this lane's points n = lane + 64 q  (periodic Hann of `win` samples, centred in n_fft)
+    // window value of this lane's points n = sl + SUB q  (periodic Hann of `win` samples, centred in n_fft)
     const int left = (N - a.win) / 2;
     float wreg[P];
 #pragma unroll
     for (int q = 0; q < P; ++q) {
-        const int n = lane + 64 * q - left;
+        const int n = sl + SUB * q - left;
         wreg[q] = (n >= 0 && n < a.win) ? 0.5f - 0.5f * cospif(2.0f * (float)n / (float)a.win) : 0.0f;
     }
 
@@ -194,70 +211,89 @@ __global__ __launch_bounds__(256, (LOG2N <= 10 ? 2 : 1)) void stft_sums_kernel(S
     const float *ts = a.t + stream * a.T + a.skip;
     const int f_begin = chunk * a.frames_per_chunk;
     const int f_end = min(f_begin + a.frames_per_chunk, a.n_frames);
+    constexpr int FSTEP = 4 * FPW;                             // frames per workgroup and iteration
 
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    // raw samples of the frame pair, fetched one frame ahead: ry/rt[q] = (y, t)[f hop + lane + 64 q - N/2],
-    // reflected at the ends (torch.stft center=True, pad_mode="reflect")
+    // raw samples of the frame pair, fetched one frame ahead: ry/rt[q] = (y, t)[f hop + sl + SUB q - N/2],
+    // reflected at the ends (torch.stft center=True, pad_mode="reflect"); frame slots past the end read frame 0
     float ry[P], rt[P];
     auto fetch = [&](int f) {
+        if (f >= f_end) f = f_begin;                        // idle slot of a multi-frame wave: harmless reload
         const int start = f * a.hop - N / 2;                // (T - skip < 2^31 - n_fft: checked by the API)
-        if (start >= 0 && start + N <= L) {                 // interior frame (wave-uniform): no index math per load
-            const float *py = ys + start + lane, *pt = ts + start + lane;
+        if (FPW == 1 && start >= 0 && start + N <= L) {     // interior frame (wave-uniform): no index math per load
+            const float *py = ys + start + sl, *pt = ts + start + sl;
 #pragma unroll
-            for (int q = 0; q < P; ++q) { ry[q] = py[64 * q]; rt[q] = pt[64 * q]; }
+            for (int q = 0; q < P; ++q) { ry[q] = py[SUB * q]; rt[q] = pt[SUB * q]; }
         } else {
 #pragma unroll
             for (int q = 0; q < P; ++q) {
-                int i = start + lane + 64 * q;
+                int i = start + sl + SUB * q;
                 i = i < 0 ? -i : i;
                 i = i >= L ? 2 * (L - 1) - i : i;
                 ry[q] = ys[i]; rt[q] = ts[i];
             }
         }
     };
-    if (f_begin + wave < f_end) fetch(f_begin + wave);
-    for (int f = f_begin + wave; f < f_end; f += 4) {
+    const int f_first = f_begin + wave * FPW;                  // this wave's first frame (slot 0)
+    if (f_first < f_end) fetch(f_first + fs);
+    for (int f0 = f_first; f0 < f_end; f0 += FSTEP) {
+        const int f = f0 + fs;
+        const bool live = f < f_end;                           // (only a multi-frame wave can have idle slots)
         f2 v[P];
 #pragma unroll
         for (int q = 0; q < P; ++q) v[q] = (f2){wreg[q] * ry[q], wreg[q] * rt[q]};
         if constexpr (LOG2N > 10) {
-            if (f + 4 < f_end) fetch(f + 4);                    // in flight during this frame's FFT
+            if (f0 + FSTEP < f_end) fetch(f + FSTEP);           // in flight during this frame's FFT
         }
-        // ---- Stockham autosort FFT, the wave's own LDS buffer between passes ----
+        // ---- Stockham autosort FFT, the frame slot's own LDS buffer between passes ----
         {
             PassTw<N, R0, 1> tw0;
-            stockham_pass<N, R0, 1, true>(v, buf, tw0, lane);
+            stockham_pass<N, R0, 1, true>(v, buf, tw0, sl);
         }
-        stockham_pass<N, R1, R0, false>(v, buf, tw1, lane);
+        stockham_pass<N, R1, R0, false>(v, buf, tw1, sl);
         if constexpr (LOG2N <= 10) {
             // n_fft <= 1024 runs two waves per SIMD (256 VGPRs): fetch late, when the big butterflies are done
-            if (f + 4 < f_end) fetch(f + 4);
+            if (f0 + FSTEP < f_end) fetch(f + FSTEP);
         }
-        stockham_pass<N, R2, R0 * R1, false>(v, buf, tw2, lane);
-        if constexpr (R3 > 1) stockham_pass<N, R3, R0 * R1 * R2, false>(v, buf, tw3, lane);
+        stockham_pass<N, R2, R0 * R1, false>(v, buf, tw2, sl);
+        if constexpr (R3 > 1) stockham_pass<N, R3, R0 * R1 * R2, false>(v, buf, tw3, sl);
         wave_lds_fence();
-        // ---- separate the two real spectra, magnitudes, distance terms for bins k = 0 .. N/2 ----
+        // ---- separate the two real spectra; distance terms for bins k = 0 .. N/2 ----
         float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
         auto bin = [&](int k) {
             const f2 zk = buf[padi(k)], zn = buf[padi((N - k) & (N - 1))];
             const float yr = 0.5f * (zk.x + zn.x), yi = 0.5f * (zk.y - zn.y);
             const float tr = 0.5f * (zk.y + zn.y), ti = 0.5f * (zn.x - zk.x);
-            const float py = fmaxf(yr * yr + yi * yi, a.eps), pt = fmaxf(tr * tr + ti * ti, a.eps);
-            const float my = __builtin_amdgcn_sqrtf(py), mt = __builtin_amdgcn_sqrtf(pt);
-            const float d = mt - my;
-            s0 += d * d;
-            s1 += pt;
-            s2 += fabsf(__builtin_amdgcn_logf(py) - __builtin_amdgcn_logf(pt));   // log2 of the POWERS
-            s3 += fabsf(d);
+            const float py0 = yr * yr + yi * yi, pt0 = tr * tr + ti * ti;
+            const float py = fmaxf(py0, a.eps), pt = fmaxf(pt0, a.eps);
+            if constexpr (MODE == 0) {
+                // auraloss.freq.STFTLoss terms: magnitudes sqrt(clamp(power, eps))
+                const float my = __builtin_amdgcn_sqrtf(py), mt = __builtin_amdgcn_sqrtf(pt);
+                const float d = mt - my;
+                s0 += d * d;
+                s1 += pt;
+                s2 += fabsf(__builtin_amdgcn_logf(py) - __builtin_amdgcn_logf(pt));   // log2 of the POWERS
+                s3 += fabsf(d);
+            } else {
+                // power-spectrogram terms (torchaudio Spectrogram(power=2) as used by code/evaluation.py:75-84):
+                // |P_y - P_t|, |log2 max(P_y, floor) - log2 max(P_t, floor)| (floor = eps), P_t, P_y
+                s0 += fabsf(py0 - pt0);
+                s1 += fabsf(__builtin_amdgcn_logf(py) - __builtin_amdgcn_logf(pt));
+                s2 += pt0;
+                s3 += py0;
+            }
         };
+        if (live) {
 #pragma unroll
-        for (int i = 0; i < P / 2; ++i) bin(lane + 64 * i);
-        if (lane == 0) bin(N / 2);
+            for (int i = 0; i < P / 2; ++i) bin(sl + SUB * i);
+            if (sl == 0) bin(N / 2);
+        }
         acc[0] += s0; acc[1] += s1; acc[2] += s2; acc[3] += s3;
         wave_lds_fence();
     }
-    // |ln mag_y - ln mag_t| = (ln 2 / 2) |log2 p_y - log2 p_t|
-    acc[2] *= 0.34657359027997264;
+    // mode 0: |ln mag_y - ln mag_t| = (ln 2 / 2) |log2 p_y - log2 p_t|;  mode 1: log10 = log10(2) log2
+    if constexpr (MODE == 0) acc[2] *= 0.34657359027997264;
+    else acc[1] *= 0.30102999566398120;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         double s = acc[c];
@@ -267,26 +303,35 @@ __global__ __launch_bounds__(256, (LOG2N <= 10 ? 2 : 1)) void stft_sums_kernel(S
     }
 }
 
-template <int LOG2N>
-static hipError_t launch_one(const StftArgs &a, hipStream_t stream)
+template <int LOG2N, int MODE>
+static hipError_t launch_mode(const StftArgs &a, hipStream_t stream)
 {
     constexpr int N = 1 << LOG2N;
-    const size_t smem = (size_t)4 * (N + N / 16) * sizeof(f2);
-    auto k = stft_sums_kernel<LOG2N>;
+    const size_t smem = (size_t)4 * Geo<N>::FPW * Geo<N>::NPAD * sizeof(f2);
+    auto k = stft_sums_kernel<LOG2N, MODE>;
     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3((unsigned)(a.B * a.chunks)), dim3(256), smem, stream, a);
     return hipGetLastError();
 }
 
+template <int LOG2N>
+static hipError_t launch_one(const StftArgs &a, hipStream_t stream)
+{
+    return a.mode == 0 ? launch_mode<LOG2N, 0>(a, stream) : launch_mode<LOG2N, 1>(a, stream);
+}
+
 hipError_t launch_stft_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int n_fft, int hop,
-                            int win, float eps, int chunks, double *out, hipStream_t stream)
+                            int win, float eps, int chunks, int mode, double *out, hipStream_t stream)
 {
     StftArgs a;
+    a.mode = mode;
     a.y = y; a.t = t; a.B = B; a.T = T; a.skip = skip; a.hop = hop; a.win = win; a.chunks = chunks; a.eps = eps; a.out = out;
     a.n_frames = (int)(1 + (T - skip) / hop);
     a.frames_per_chunk = (a.n_frames + chunks - 1) / chunks;
     switch (n_fft) {
+    case 64: return launch_one<6>(a, stream);
+    case 128: return launch_one<7>(a, stream);
     case 256: return launch_one<8>(a, stream);
     case 512: return launch_one<9>(a, stream);
     case 1024: return launch_one<10>(a, stream);

@@ -395,3 +395,56 @@ class MRSTFTLoss(torch.nn.Module):
 
     def forward(self, output, target):
         return self._terms(output, target, 0, True).float()
+
+
+SPEC_SCALES = (2048, 1024, 512, 256, 128, 64)     # code/evaluation.py:23
+SPEC_LOG_FLOOR = 1e-5                              # code/evaluation.py:44
+
+
+@torch.no_grad()
+def spec_sums(output, target, skip=0, n_fft=1024, hop=None, win_length=None, log_floor=SPEC_LOG_FLOOR):
+    """Per-stream sums of the power-spectrogram terms (ntm_spec_sums): (B,4) fp64 =
+    sum |P_y - P_t| | sum |log10 max(P_y,f) - log10 max(P_t,f)| | sum P_t | sum P_y, and the cells per stream."""
+    hop = int(n_fft) // 4 if hop is None else int(hop)
+    win_length = int(n_fft) if win_length is None else int(win_length)
+    y = _as_bt(output, "spec_sums")
+    t = _as_bt(target, "spec_sums")
+    B, T = y.shape
+    n_frames = 1 + (T - int(skip)) // hop
+    chunks = max(1, min(-(-2048 // max(B, 1)), n_frames // 32))
+    out = torch.empty(B, 4 * chunks, 4, device=y.device, dtype=torch.float64)
+    rc = _lib.lib().ntm_spec_sums(ptr(y), ptr(t), B, T, int(skip), int(n_fft), hop, win_length, float(log_floor), chunks,
+                                  ptr(out), _lib.current_stream())
+    _lib.check(rc, "ntm_spec_sums")
+    return out.sum(dim=1), n_frames * (int(n_fft) // 2 + 1)
+
+
+class ValLossSupervised(torch.nn.Module):
+    """`val_loss_supervised` of code/evaluation.py:18-100 (the validation metric bundle of the adversarial run) on
+    the device, for what can be pinned here: `ms_spec_loss` / `ms_log_spec_loss` (sum over the six scales of the
+    mean absolute difference of the power spectrograms / of their clamped log10; `TimeFreqConverter` is torchaudio's
+    Spectrogram(n_fft, hop = n_fft/4, power 2) = torch.stft, golden g13), `ESR`, `ESRDCPre`, `MSE`.  The two mel
+    entries need librosa's filter bank, which is not available to pin: they are not produced.
+    forward(output, target) with (B, T) or (B, 1, T) tensors -> dict of python floats."""
+
+    def __init__(self, spec_scales=SPEC_SCALES, log_eps=SPEC_LOG_FLOOR):
+        super().__init__()
+        self.spec_scales, self.log_eps = tuple(spec_scales), log_eps
+
+    @torch.no_grad()
+    def forward(self, output, target):
+        if output.dim() == 2:
+            output, target = output.unsqueeze(1), target.unsqueeze(1)
+        losses = {"ms_spec_loss": 0.0, "ms_log_spec_loss": 0.0}
+        for n_fft in self.spec_scales:
+            s, cells = spec_sums(output, target, 0, n_fft, log_floor=self.log_eps)
+            tot = s.sum(dim=0) / (cells * s.shape[0])
+            losses["ms_spec_loss"] += float(tot[0])
+            losses["ms_log_spec_loss"] += float(tot[1])
+        n = output.numel()
+        e = esr_sums(output, target).sum(dim=0)
+        losses["ESR"] = float((e[0] / n) / (e[1] / n + ESR_EPS))
+        losses["MSE"] = float(e[0] / n)
+        d = esr_dcpre_sums(output, target).sum(dim=0)
+        losses["ESRDCPre"] = float((d[0] / n) / (d[1] / n + ESR_EPS))
+        return losses

@@ -217,6 +217,52 @@ def mrstft_per_segment(y, t, skip=0, resolutions=MRSTFT_RESOLUTIONS):
     return total / len(resolutions)
 
 
+SPEC_SCALES = (2048, 1024, 512, 256, 128, 64)        # code/evaluation.py:23
+SPEC_LOG_FLOOR = 1e-5                                   # code/evaluation.py:44
+
+
+def spec_sums(y, t, skip=0, n_fft=1024, hop=None, win_length=None, log_floor=SPEC_LOG_FLOOR):
+    """Per-stream sums of the POWER-spectrogram terms of code/evaluation.py:75-84 (`TimeFreqConverter` =
+    torchaudio.transforms.Spectrogram(n_fft, hop_length=n_fft//4), power 2; torchaudio is un-vendored here: its
+    Spectrogram is torch.stft with a periodic Hann window of n_fft samples, centred, reflect padding -- pinned to
+    torch.stft by golden g13).  Returns [B,4] float64: sum |P_y - P_t| | sum |log10 max(P_y,f) - log10 max(P_t,f)| |
+    sum P_t | sum P_y, and the number of (bin, frame) cells per stream."""
+    hop = n_fft // 4 if hop is None else hop
+    win_length = n_fft if win_length is None else win_length
+    y = np.asarray(y, np.float64)[:, skip:]
+    t = np.asarray(t, np.float64)[:, skip:]
+    B, L = y.shape
+    win = np.zeros(n_fft)
+    left = (n_fft - win_length) // 2
+    win[left:left + win_length] = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(win_length) / win_length)
+    n_frames = 1 + L // hop
+    idx = np.arange(n_frames)[:, None] * hop + np.arange(n_fft)[None, :]
+
+    def power(x):
+        xp = np.pad(x, ((0, 0), (n_fft // 2, n_fft // 2)), mode="reflect")
+        X = np.fft.rfft(xp[:, idx] * win, axis=-1)
+        return X.real ** 2 + X.imag ** 2
+
+    out = np.empty((B, 4))
+    for b in range(B):
+        py, pt = power(y[b:b + 1]), power(t[b:b + 1])
+        out[b] = [np.abs(py - pt).sum(),
+                  np.abs(np.log10(np.maximum(py, log_floor)) - np.log10(np.maximum(pt, log_floor))).sum(), pt.sum(), py.sum()]
+    return out, n_frames * (n_fft // 2 + 1)
+
+
+def ms_spec_losses(y, t, scales=SPEC_SCALES):
+    """`ms_spec_loss` and `ms_log_spec_loss` of val_loss_supervised.forward (code/evaluation.py:75-84) over the
+    whole batch: SUM over the scales of the mean absolute difference of the power spectrograms / of their
+    log10 (clamped at 1e-5)."""
+    lin = log = 0.0
+    for n_fft in scales:
+        s, cells = spec_sums(y, t, 0, n_fft)
+        lin += s[:, 0].sum() / (cells * len(s))
+        log += s[:, 1].sum() / (cells * len(s))
+    return lin, log
+
+
 def _lin_interp(xk, yk, xn):
     """scipy.interpolate.interp1d(kind='linear')._call_linear restated: knots xk (increasing), values yk [..., K]."""
     idx = np.clip(np.searchsorted(xk, xn), 1, len(xk) - 1)

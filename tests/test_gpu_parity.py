@@ -806,3 +806,34 @@ def test_c_abi_from_a_plain_cpp_process(ntm, tmp_path):
     m = make_rnn(ntm, W_G, "auto")
     m.initialize_hidden()
     assert np.array_equal(m(dev(x).unsqueeze(1)).cpu().numpy()[:, 0], y)      # same kernel, same bits
+
+
+@pytest.mark.parametrize("n_fft", [64, 128, 256, 2048])
+def test_spec_sums_vs_oracle(ntm, n_fft):
+    """Power-spectrogram sums (code/evaluation.py:75-84) incl. the small scales, where a wave transforms 4 (n_fft 64)
+    or 2 (n_fft 128) frames side by side; and the auraloss-style sums at those small sizes."""
+    g = load("g10_mrstft.npz")
+    y, t = dev(g["pred"]).unsqueeze(1), dev(g["targ"]).unsqueeze(1)
+    for skip in (0, 777):
+        s, cells = ntm.spec_sums(y, t, skip, n_fft)
+        so, cells_o = oracle.spec_sums(g["pred"], g["targ"], skip, n_fft)
+        assert cells == cells_o and np.allclose(s.cpu().numpy(), so, rtol=1e-4), (n_fft, skip, s.cpu().numpy() / so - 1)
+    if n_fft <= 128:
+        s, cells = ntm.stft_sums(y, t, 100, n_fft, n_fft // 4, n_fft - 4)
+        so, _ = oracle.stft_sums(g["pred"], g["targ"], 100, n_fft, n_fft // 4, n_fft - 4)
+        assert np.allclose(s.cpu().numpy(), so, rtol=1e-4)
+
+
+def test_val_loss_supervised_bundle(ntm):
+    """The validation metric bundle of code/evaluation.py:18-100 (without its mel entries) against golden g13
+    (torch.stft) and the oracle."""
+    g10, g = load("g10_mrstft.npz"), load("g13_ms_spec.npz")
+    y, t = dev(g10["pred"]), dev(g10["targ"])
+    got = ntm.ValLossSupervised()(y, t)
+    assert abs(got["ms_spec_loss"] / float(g["ms_spec_loss"]) - 1) < 1e-4
+    assert abs(got["ms_log_spec_loss"] / float(g["ms_log_spec_loss"]) - 1) < 1e-4
+    e = oracle.esr_sums(g10["pred"], g10["targ"]).sum(0); n = g10["pred"].size
+    assert abs(got["MSE"] - e[0] / n) < 1e-9 * e[0] / n and abs(got["ESR"] - (e[0] / n) / (e[1] / n + 1e-5)) < 1e-9
+    d = oracle.esr_dcpre_sums(g10["pred"], g10["targ"]).sum(0)
+    assert abs(got["ESRDCPre"] - (d[0] / n) / (d[1] / n + 1e-5)) < 1e-4 * got["ESRDCPre"]
+    assert "mel_spec_loss" not in got

@@ -178,3 +178,11 @@ def test_g10_mrstft_against_torch_stft():
         assert np.allclose(s[:, 2] / cells, g["terms"][:, r, 1], rtol=2e-5)
         assert np.allclose(s[:, 3] / cells, g["terms"][:, r, 2], rtol=2e-5)
     assert np.allclose(oracle.mrstft_per_segment(g["pred"], g["targ"], skip), g["loss"], rtol=1e-5)
+
+
+def test_g13_power_spectrogram_metrics_against_torch_stft():
+    """code/evaluation.py:75-84 (ms_spec_loss, ms_log_spec_loss over six scales down to n_fft = 64): the oracle's fp64
+    restatement against torch.stft-based values (tools/make_goldens_stft.py)."""
+    g10, g = load("g10_mrstft.npz"), load("g13_ms_spec.npz")
+    lin, log = oracle.ms_spec_losses(g10["pred"], g10["targ"])
+    assert abs(lin / float(g["ms_spec_loss"]) - 1) < 1e-6 and abs(log / float(g["ms_log_spec_loss"]) - 1) < 1e-6

@@ -54,3 +54,26 @@ if __name__ == "__main__":
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "g10_mrstft.npz"), pred=pred, targ=targ, skip=skip,
                         res=np.array(RES), terms=terms, loss=loss)
     print(terms, loss)
+
+
+# ---- second part: the power-spectrogram validation metrics of code/evaluation.py:75-84 (TimeFreqConverter wraps
+# torchaudio.transforms.Spectrogram(n_fft, hop_length=n_fft//4), i.e. torch.stft with a periodic Hann window of
+# n_fft samples and power 2; torchaudio itself is not installed here) -> tests/golden/g13_ms_spec.npz
+def ms_spec_goldens():
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g10_mrstft.npz"))
+    out, tgt = torch.from_numpy(g["pred"]), torch.from_numpy(g["targ"])
+    scales = (2048, 1024, 512, 256, 128, 64)
+    lin, log, per_scale = 0.0, 0.0, []
+    for n in scales:
+        P = lambda x: torch.stft(x, n, n // 4, n, torch.hann_window(n), return_complex=True).abs() ** 2      # noqa: E731
+        px, py = P(out), P(tgt)
+        a = torch.nn.functional.l1_loss(px, py).item()
+        b = torch.nn.functional.l1_loss(torch.log10(torch.clamp(px, 1e-5)), torch.log10(torch.clamp(py, 1e-5))).item()
+        per_scale.append((a, b)); lin += a; log += b
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "g13_ms_spec.npz"), scales=np.array(scales),
+                        per_scale=np.array(per_scale), ms_spec_loss=lin, ms_log_spec_loss=log)
+    print("ms_spec", lin, log, per_scale)
+
+
+if __name__ == "__main__":
+    ms_spec_goldens()
