@@ -193,10 +193,11 @@ def main():
 
     def one_pass(target, evs=(ev0, ev1)):
         """One step: model.predict(x) (code/model.py:218-246, unrolled so the events bracket the main launch) and,
-        when a target is given, the ESR sums + reduction of code/test-model.py:386-398 on the side stream -- the
+        when a target is given, the ESR sums and this rank's loss scalars (code/test-model.py:386-398) on the side stream -- the
         next step's launches do not wait for them (the K timed steps are bracketed by synchronisation on both
         sides; inside, the HBM-bound loss leg of step k overlaps the compute-bound GRU launch of step k+1).
-        -> (y, pending loss reduction or None)"""
+        -> (y, this rank's loss scalars (device) or None); the job-wide all-reduce of all K steps' scalars is ONE RCCL
+        call issued before the closing synchronisation"""
         model.initialize_hidden()
         model.warm_start()
         model.hidden = model.hidden.expand(1, B, 64).contiguous()
@@ -210,14 +211,15 @@ def main():
             with torch.cuda.stream(side):
                 s = esr_sums(y, target, skip=INIT_LEN)
                 n = T - INIT_LEN
-                pend = D.reduce_loss_sums_begin((s[:, 0] / n) / (s[:, 1] / n + ESR_EPS), s)
+                pend = D.local_loss_sums((s[:, 0] / n) / (s[:, 1] / n + ESR_EPS), s)
         return y, pend
 
     target = None
     for _ in range(max(a.warmup, 0)):
         y, pend = one_pass(target)
         if pend is not None:
-            D.reduce_loss_sums_end(pend)
+            torch.cuda.current_stream().wait_stream(side)
+            D.reduce_many([pend])
         if target is None:
             target = y.clone()
     if target is None:                      # --warmup 0: still need the determinism target
@@ -232,10 +234,10 @@ def main():
         y, pend = one_pass(target, step_evs[k])
         pends.append(pend)
     torch.cuda.current_stream().wait_stream(side)
+    results = D.reduce_many(pends)          # ONE all-reduce of the K x 4 scalars (RCCL), inside the timed region
     torch.cuda.synchronize()
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)
-    results = [D.reduce_loss_sums_end(p) for p in pends]
     res = results[-1] if results else None
     assert all(r["mean_segment_loss"] == results[0]["mean_segment_loss"] for r in results)     # every step: same numbers
     kern_ms = [e0.elapsed_time(e1) for e0, e1 in step_evs]
@@ -320,7 +322,7 @@ def main():
         "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": f"GRU-HS[64] CHOWTAPE weights, {B} segments x {T} samples fp32 per GPU, "
-                               f"predict (warm-start + persistent GRU kernel) + ESR sums + all-reduce on a side stream, overlapping the next step's launch",
+                               f"predict (warm-start + persistent GRU kernel) + ESR sums on a side stream under the next step's launch + one all-reduce of the per-step loss scalars",
                    "segments_per_gpu": B, "samples_per_segment": T, "kernel": a.variant,
                    "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
         "realtime_factor": total_samples / elapsed / FS,

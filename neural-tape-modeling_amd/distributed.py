@@ -54,32 +54,32 @@ def reduce_loss_sums(per_segment_loss, err_sums=None, group=None):
             "sum_err2": float(v[2]), "sum_tgt2": float(v[3])}
 
 
-def reduce_loss_sums_begin(per_segment_loss, err_sums=None, group=None):
-    """First half of reduce_loss_sums: builds the 4 fp64 scalars and issues the SUM all-reduce on the CURRENT
-    stream without fetching the result -- the caller keeps launching work and calls reduce_loss_sums_end later."""
+def local_loss_sums(per_segment_loss, err_sums=None):
+    """This rank's 4 fp64 scalars [sum of per-segment losses, segment count, sum err^2, sum tgt^2] as a device
+    tensor on the CURRENT stream -- no collective, no host synchronisation (bench.py keeps one per timed step
+    and reduces them together with reduce_many)."""
     dev = per_segment_loss.device
     parts = [per_segment_loss.double().sum().reshape(1),
              torch.full((1,), float(per_segment_loss.numel()), dtype=torch.float64, device=dev),
              err_sums.double().sum(dim=0) if err_sums is not None else torch.zeros(2, dtype=torch.float64, device=dev)]
-    v = torch.cat(parts)
+    return torch.cat(parts)
+
+
+def reduce_many(local_vectors, group=None):
+    """Job-wide results for a list of local_loss_sums vectors: ONE SUM all-reduce of the stacked (K,4) tensor on the
+    current stream, then one fetch.  -> list of the dicts reduce_loss_sums returns."""
+    if not local_vectors:
+        return []
+    V = torch.stack(local_vectors)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
-    ev = None
-    if v.is_cuda:
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(v.device))
-    return v, ev
-
-
-def reduce_loss_sums_end(pending):
-    """Second half: wait for the stream that produced the reduced scalars, then fetch them."""
-    v, ev = pending
-    if ev is not None:
-        ev.synchronize()
-    v = v.cpu()
-    n = int(v[1].item())
-    return {"mean_segment_loss": float(v[0] / max(n, 1)), "segments": n,
-            "sum_err2": float(v[2]), "sum_tgt2": float(v[3])}
+        dist.all_reduce(V, op=dist.ReduceOp.SUM, group=group)
+    V = V.cpu()
+    out = []
+    for v in V:
+        n = int(v[1].item())
+        out.append({"mean_segment_loss": float(v[0] / max(n, 1)), "segments": n,
+                    "sum_err2": float(v[2]), "sum_tgt2": float(v[3])})
+    return out
 
 
 def max_over_ranks(value, device):

@@ -33,6 +33,9 @@ def _worker(rank, world, port, y, t, skip, q):
     n = y.shape[1] - skip
     per_seg = (s[:, 0] / n) / (s[:, 1] / n + ntm_amd.model.ESR_EPS)
     res = D.reduce_loss_sums(per_seg, s)
+    # the stacked form bench.py uses: K steps' local scalars, ONE all-reduce
+    many = D.reduce_many([D.local_loss_sums(per_seg, s), D.local_loss_sums(per_seg, s)])
+    assert many[0] == res and many[1] == res
     tmax = D.max_over_ranks(float(rank + 1), torch.device("cpu"))
     D.barrier()
     q.put((rank, res, tmax))
@@ -66,12 +69,13 @@ def test_two_rank_loss_reduction_matches_single_process():
         assert tmax == 2.0
 
 
-def test_reduce_loss_sums_two_phase_single_process():
-    """begin/end pair (used by bench.py to keep the loss leg off the launch path) == the one-call form."""
+def test_local_sums_and_reduce_many_single_process():
+    """local_loss_sums + reduce_many (used by bench.py to keep the loss leg off the launch path) == the one-call form."""
     import torch
     from ntm_amd import distributed as D
     per = torch.tensor([0.1, 0.2, 0.4], dtype=torch.float64)
     sums = torch.tensor([[1.0, 2.0], [3.0, 4.0], [5.0, 6.0]], dtype=torch.float64)
     a = D.reduce_loss_sums(per, sums)
-    b = D.reduce_loss_sums_end(D.reduce_loss_sums_begin(per, sums))
-    assert a == b and abs(a["mean_segment_loss"] - 0.7 / 3) < 1e-15 and a["sum_err2"] == 9.0 and a["sum_tgt2"] == 12.0
+    b = D.reduce_many([D.local_loss_sums(per, sums), D.local_loss_sums(2 * per, None)])
+    assert a == b[0] and abs(a["mean_segment_loss"] - 0.7 / 3) < 1e-15 and a["sum_err2"] == 9.0 and a["sum_tgt2"] == 12.0
+    assert abs(b[1]["mean_segment_loss"] - 1.4 / 3) < 1e-15 and b[1]["sum_err2"] == 0.0 and D.reduce_many([]) == []
