@@ -297,7 +297,8 @@ class SegmentFeeder:
 
     @torch.no_grad()
     def predict_streamed(self, model, b0, b1, chunk=8192, device="cuda", out_host=None):
-        """GRU predict over segments b0..b1-1 straight from pinned host memory, pipelined along TIME: the batch goes to
+        """GRU (or DiffDelGRU: the delay trajectory travels too) predict over segments b0..b1-1 straight from pinned
+        host memory, pipelined along TIME: the batch goes to
         the device in chunks of `chunk` samples x all segments (pitched DMA copies, ntm_copy2d_async, on a side stream)
         and the kernel for chunk c runs while chunk c+1 is in flight -- every launch still sees the full batch (the
         matrix-pipe kernel needs thousands of streams per launch; splitting the batch by segments instead would starve
@@ -309,9 +310,16 @@ class SegmentFeeder:
         assert not self.demodulate, "demodulated targets take the per-item path (batches())"
         B, L = b1 - b0, self.length
         lib = _lib.lib()
+        from .model import DiffDelRNN
+        is_dd = isinstance(model, DiffDelRNN)
         x = torch.empty(B, 1, L, device=device, dtype=torch.float32)
         t = None if self.input_only else torch.empty(B, 1, L, device=device, dtype=torch.float32)
         y = torch.empty(B, 1, L, device=device, dtype=torch.float32)
+        dtr = None
+        if is_dd:        # the delay trajectory [seconds] travels with the audio, chunk by chunk
+            assert all(self._audio[self.examples[i]["idx"]][2] is not None for i in range(b0, b1)), \
+                "DiffDelGRU needs delay trajectories (stereo dataset or side-cars)"
+            dtr = torch.empty(B, 1, L, device=device, dtype=torch.float32)
         runs = self.runs(b0, b1)
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream(device=device)
@@ -319,10 +327,12 @@ class SegmentFeeder:
 
         def send(c0, c1):
             for k0, n, idx, off in runs:
-                for which, dst in ((0, x), (1, t)):
+                for which, dst in ((0, x), (1, t), (2, dtr)):
                     if dst is None:
                         continue
                     src = self._audio[idx][which]
+                    if which == 2:
+                        src = src["traj_f32"]
                     rc = lib.ntm_copy2d_async(dst[k0, 0, c0:].data_ptr(), 4 * L, src[0, off + c0:].data_ptr(), 4 * L,
                                               4 * (c1 - c0), n, 0, side.cuda_stream)
                     _lib.check(rc, "ntm_copy2d_async")
@@ -330,10 +340,17 @@ class SegmentFeeder:
             ev.record(side)
             return ev
 
-        model.initialize_hidden()
-        model.warm_start()
-        if B != 1:
-            model.hidden = model.hidden.expand(1, B, model.hidden_size).contiguous()
+        if is_dd:
+            model.initialize_hidden(1, model.max_delay)
+            model.warm_start()
+            if B != 1:
+                model.hidden = model.hidden.expand(1, B, model.hidden_size).contiguous()
+                model.diffdel.buffer = model.diffdel.buffer.expand(B, 1, -1).contiguous()
+        else:
+            model.initialize_hidden()
+            model.warm_start()
+            if B != 1:
+                model.hidden = model.hidden.expand(1, B, model.hidden_size).contiguous()
         bounds = [(c0, min(L, c0 + chunk)) for c0 in range(0, L, chunk)]
         ev = send(*bounds[0])
         back = torch.cuda.Stream(device=device) if out_host is not None else None
@@ -342,7 +359,10 @@ class SegmentFeeder:
         for i, (c0, c1) in enumerate(bounds):
             nxt = send(*bounds[i + 1]) if i + 1 < len(bounds) else None
             cur.wait_event(ev)
-            model.forward_into(x[:, 0, c0:c1], y[:, 0, c0:c1])
+            if is_dd:    # GRU + delay line on the chunk (state of both carried); trajectory seconds -> samples
+                y[:, :, c0:c1] = model.forward(x[:, :, c0:c1], dtr[:, :, c0:c1] * float(self.fs))[0]
+            else:
+                model.forward_into(x[:, 0, c0:c1], y[:, 0, c0:c1])
             if back is not None:
                 done = torch.cuda.Event()
                 done.record(cur)
@@ -353,7 +373,7 @@ class SegmentFeeder:
             ev = nxt
         if back is not None:
             cur.wait_stream(back)                               # a sync of the caller's stream covers the copies back
-        for a in (x, t):
+        for a in (x, t, dtr):
             if a is not None:
                 a.record_stream(side)
         return y, x, t

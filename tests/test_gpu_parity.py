@@ -837,3 +837,27 @@ def test_val_loss_supervised_bundle(ntm):
     d = oracle.esr_dcpre_sums(g10["pred"], g10["targ"]).sum(0)
     assert abs(got["ESRDCPre"] - (d[0] / n) / (d[1] / n + 1e-5)) < 1e-4 * got["ESRDCPre"]
     assert "mel_spec_loss" not in got
+
+
+def test_streamed_predict_diffdel(ntm, tmp_path):
+    """Time-pipelined predict for DiffDelGRU (audio + delay trajectory sent chunk by chunk, GRU and delay-line state
+    carried) == the resident one-shot predict, bit for bit."""
+    from scipy.io import wavfile
+    from ntm_amd.feeder import SegmentFeeder
+    g = load("g12_delay_analysis.npz")
+    fs, N = int(g["fs"]), len(g["in0"])
+    d = tmp_path / "Wow" / "Test"
+    d.mkdir(parents=True)
+    rng = np.random.default_rng(9)
+    audio = rng.uniform(-0.4, 0.4, N).astype(np.float32)
+    wavfile.write(str(d / "input_0_.wav"), fs, np.stack([audio, g["in0"]], 1))
+    wavfile.write(str(d / "target_0_.wav"), fs, np.stack([0.5 * audio, g["out0"]], 1))
+    L = 7000
+    f = SegmentFeeder(str(tmp_path / "Wow"), subset="test", length=L)
+    m = ntm.harness.build_model(W_D, max_delay_seconds=f.max_delay, fs=fs)
+    xin, tgt, dt, _ = next(f.batches(len(f), "cuda"))
+    want, _ = m.predict(xin, dt * fs)
+    for chunk in (2048, 1500, 7000):
+        y, x2, t2 = f.predict_streamed(m, 0, len(f), chunk=chunk)
+        torch.cuda.synchronize()
+        assert torch.equal(x2, xin) and torch.equal(y, want), chunk

@@ -59,7 +59,7 @@ def main(argv=None):
     per = {"ESR": [], "DCPreESR": [], "MultiSTFT": []}
     mrstft = ntm_amd.MRSTFTLoss()
     def batches():
-        if is_dd or a.DEMODULATE or a.ADD_DELAY or a.STREAM_CHUNK <= 0:
+        if a.DEMODULATE or a.ADD_DELAY or a.STREAM_CHUNK <= 0:
             for xin, tgt, dt, _ in feeder.batches(a.BATCH_SIZE, "cuda", rank, world):
                 if is_dd:
                     assert dt is not None, "DiffDelGRU needs trajectory_<id>_*.npy side-cars"
@@ -68,7 +68,7 @@ def main(argv=None):
                     out = model.predict(xin)
                 yield xin, tgt, out, dt
         else:
-            # GRU: predict straight from the feeder's pinned files, H2D copies pipelined along time under the launches
+            # predict straight from the feeder's pinned files, H2D copies pipelined along time under the launches
             lo, hi = D.shard_range(len(feeder), rank, world)
             for b0 in range(lo, hi, a.BATCH_SIZE):
                 out, xin, tgt = feeder.predict_streamed(model, b0, min(hi, b0 + a.BATCH_SIZE), chunk=a.STREAM_CHUNK)
