@@ -18,32 +18,50 @@ __global__ __launch_bounds__(256) void delay_check_kernel(const float *d, int64_
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
+// one output sample: y[n] = w_b x[n-k-1] + w_a x[n-k] with the reference's tap order and rounding
+__device__ __forceinline__ float delay_sample(const float *xb, const float *bb, int D, int64_t n, float dn)
+{
+#pragma clang fp contract(off)   // products and the sum must round separately (bit-exact parity)
+    const float kf = floorf(dn);
+    float acc = 0.0f;
+#pragma unroll
+    for (int tap = 1; tap >= 0; --tap) {          // m = k+1 first, then m = k (reference sum order)
+        const float mf = kf + (float)tap;
+        if (mf < 0.0f || mf > (float)D) continue;
+        const float w = 1.0f - fabsf(mf - dn);
+        if (!(w > 0.0f)) continue;
+        const int64_t src = n - (int64_t)mf;
+        const float xv = src >= 0 ? xb[src] : bb[D + src];
+        const float prod = w * xv;
+        acc = acc + prod;
+    }
+    return acc;
+}
+
+// thread -> 4 consecutive samples: d is read and y written with 16-byte accesses when the rows allow it
+// (HBM-bound pass: 12 B/sample + the two gathered taps, which hit L2)
 __global__ __launch_bounds__(256) void delay_apply_kernel(const float *x, const float *d, float *y, int64_t B,
                                                           int64_t T, const float *buf, int D, int warmup,
                                                           const int32_t *flag)
 {
-#pragma clang fp contract(off)   // products and the sum must round separately (bit-exact parity)
     if (flag && *flag) return;
     const int64_t b = blockIdx.x;
     const float *xb = x + b * T, *db = d + b * T, *bb = buf + b * (int64_t)D;
     float *yb = y + b * T;
-    for (int64_t n = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; n < T; n += (int64_t)gridDim.y * blockDim.x) {
-        if (warmup) { yb[n] = xb[n]; continue; }
-        const float dn = db[n];
-        const float kf = floorf(dn);
-        float acc = 0.0f;
+    const bool vec = ((T & 3) == 0) && (((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(y) |
+                                          reinterpret_cast<uintptr_t>(x)) & 15) == 0);
+    for (int64_t n0 = 4 * ((int64_t)blockIdx.y * blockDim.x + threadIdx.x); n0 < T; n0 += 4 * (int64_t)gridDim.y * blockDim.x) {
+        if (vec) {                                   // n0 + 3 < T because T is a multiple of 4
+            if (warmup) { *(f32x4 *)(yb + n0) = *(const f32x4 *)(xb + n0); continue; }
+            const f32x4 dv = *(const f32x4 *)(db + n0);
+            f32x4 out;
 #pragma unroll
-        for (int tap = 1; tap >= 0; --tap) {          // m = k+1 first, then m = k (reference sum order)
-            const float mf = kf + (float)tap;
-            if (mf < 0.0f || mf > (float)D) continue;
-            const float w = 1.0f - fabsf(mf - dn);
-            if (!(w > 0.0f)) continue;
-            const int64_t src = n - (int64_t)mf;
-            const float xv = src >= 0 ? xb[src] : bb[D + src];
-            const float prod = w * xv;
-            acc = acc + prod;
+            for (int c = 0; c < 4; ++c) out[c] = delay_sample(xb, bb, D, n0 + c, dv[c]);
+            *(f32x4 *)(yb + n0) = out;
+        } else {
+            for (int c = 0; c < 4 && n0 + c < T; ++c)
+                yb[n0 + c] = warmup ? xb[n0 + c] : delay_sample(xb, bb, D, n0 + c, db[n0 + c]);
         }
-        yb[n] = acc;
     }
 }
 
@@ -73,7 +91,7 @@ hipError_t launch_delay(const float *x, const float *d, float *y, int64_t B, int
                         int warmup, float *scratch, int32_t *err_flag, hipStream_t stream)
 {
     if (B == 0 || T == 0) return hipSuccess;
-    const unsigned gx = (unsigned)((T + 255) / 256 > 4096 ? 4096 : (T + 255) / 256);
+    const unsigned gx = (unsigned)((T + 1023) / 1024 > 4096 ? 4096 : (T + 1023) / 1024);     // 4 samples per thread
     if (err_flag) {
         hipError_t e = hipMemsetAsync(err_flag, 0, sizeof(int32_t), stream);
         if (e != hipSuccess) return e;
