@@ -8,7 +8,8 @@
  * of these and INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
  *
  * Conventions (all entry points):
- *   - every pointer is a DEVICE pointer owned by the caller (fp32 unless noted); nothing is
+ *   - every pointer is a DEVICE pointer owned by the caller (fp32) unless an entry point says otherwise (small
+ *     host-side parameter arrays, the host side of ntm_copy2d_async); nothing is
  *     allocated or freed inside; no global state (carried state lives in the caller's h_state /
  *     dl_state buffers), so calls are re-entrant;
  *   - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL = default);
