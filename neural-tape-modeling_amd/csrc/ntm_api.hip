@@ -55,8 +55,26 @@ int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, 
     if (variant == NTM_GRU_VALU && (reinterpret_cast<uintptr_t>(w_hh) & 15))
         return fail(NTM_EINVAL, "ntm_gru_forward: NTM_GRU_VALU reads W_hh with 16-byte loads; w_hh must be 16-byte aligned");
     ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, x_stride_b, y_stride_b, nullptr, 0, 0};
-    if (variant == NTM_GRU_AUTO) variant = B <= NTM_GRU_LAT_MAX_B ? NTM_GRU_LAT : NTM_GRU_MFMA2;
     hipError_t e;
+    if (variant == NTM_GRU_AUTO) {
+        // B <= 1024: the low-latency kernel.  Otherwise the matrix-pipe kernel; when B is a whole number of full
+        // device rounds (16 streams x CUs) plus a remainder the low-latency kernel can take, the remainder goes there
+        // instead of opening another round of workgroups (B = 4112: 5.4 ms instead of 7.2 per 4096 steps).
+        const int64_t round = 16 * (int64_t)ntm::device_cus();
+        const int64_t full = (B / round) * round, rem = B - full;
+        if (B <= NTM_GRU_LAT_MAX_B) variant = NTM_GRU_LAT;
+        else if (full > 0 && rem > 0 && rem <= NTM_GRU_LAT_MAX_B) {
+            ntm::GruArgs a0 = a, a1 = a;
+            a0.B = full;
+            a1.B = rem;
+            a1.x = x + full * x_stride_b;
+            a1.y = y + full * y_stride_b;
+            a1.h_state = h_state ? h_state + full * NTM_HIDDEN : nullptr;
+            e = ntm::launch_gru_mfma2(a0, (hipStream_t)stream);
+            if (e == hipSuccess) e = ntm::launch_gru_lat(a1, (hipStream_t)stream);
+            return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_gru_forward");
+        } else variant = NTM_GRU_MFMA2;
+    }
     switch (variant) {
         case NTM_GRU_MFMA: e = ntm::launch_gru_mfma(a, (hipStream_t)stream); break;
         case NTM_GRU_VALU: e = ntm::launch_gru_valu(a, (hipStream_t)stream); break;

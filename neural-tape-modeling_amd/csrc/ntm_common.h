@@ -39,6 +39,16 @@ struct GruArgs {
 }  // namespace ntm
 
 namespace ntm {
+// compute units of the current device (256 on MI355X); the launch heuristics count stream groups against it
+inline int device_cus()
+{
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+        return n;
+    return 256;
+}
+
 hipError_t launch_gru_mfma(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_valu(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream);

@@ -861,3 +861,24 @@ def test_streamed_predict_diffdel(ntm, tmp_path):
         y, x2, t2 = f.predict_streamed(m, 0, len(f), chunk=chunk)
         torch.cuda.synchronize()
         assert torch.equal(x2, xin) and torch.equal(y, want), chunk
+
+
+def test_auto_splits_a_ragged_batch_between_the_two_kernels(ntm):
+    """B = one full device round (16 streams x CUs) + a small remainder: AUTO runs the matrix-pipe kernel on the full
+    round and the low-latency kernel on the remainder; every stream (state included) matches the oracle."""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    B, T = 16 * cus + 21, 96
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-0.5, 0.5, (B, T)).astype(np.float32)
+    h0 = rng.uniform(-0.5, 0.5, (B, 64)).astype(np.float32)
+    idx = np.r_[0:3, 16 * cus - 2:16 * cus + 21]
+    yo, ho = oracle.gru_forward(oracle_weights(W_G), x[idx], h0[idx].copy())
+    m = make_rnn(ntm, W_G, "auto")
+    m.hidden = dev(h0).unsqueeze(0)
+    y = m(dev(x).unsqueeze(1)).cpu().numpy()[:, 0]
+    assert np.abs(y[idx] - yo).max() < TOL and np.abs(m.hidden.cpu().numpy()[0][idx] - ho).max() < TOL
+    # the two halves really come from different kernels: they agree with the explicit variants bit for bit
+    for variant, sl in (("mfma2", slice(0, 16 * cus)), ("lat", slice(16 * cus, B))):
+        mv = make_rnn(ntm, W_G, variant)
+        mv.hidden = dev(h0[sl]).unsqueeze(0)
+        assert np.array_equal(mv(dev(x[sl]).unsqueeze(1)).cpu().numpy()[:, 0], y[sl]), variant
