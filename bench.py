@@ -143,6 +143,12 @@ def side_workload(a):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{name}, {B} segments x {T} samples fp32"},
         "device_ms_per_step": float(np.mean(ms)), "bytes_per_sample": bytes_per_sample,
+        # whole-step roofline (several kernels per step): algorithmic flops over the device time of a step against the
+        # fp32 peak; DiffDelGRU = the GRU flops (the delay line adds 3 flop/sample), TCN = 43 520 FMA per sample
+        "roofline": (lambda fl: {"bound": "mfma", "achieved": fl * B * T / (np.mean(ms) * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": fl * B * T / (np.mean(ms) * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                                 "traffic": None, "flop_per_sample": fl})(
+            FLOP_PER_SAMPLE if a.workload == "diffdel" else 2 * (13 * 32 + 32 + 3 * (32 * 13 * 32 + 32 * 32) + 32)),
         "checks": {"deterministic": bool(torch.equal(y, y0)),
                    "stream0_vs_oracle_max_abs": float(np.abs(y[0, 0].cpu().numpy() - ref0).max())}}))
 
