@@ -120,9 +120,14 @@ def side_workload(a):
         model = ntm_amd.TCN().to(dev)
         run = lambda: model(x)                                               # noqa: E731
         name, bytes_per_sample = "TCN 4x(k13, dil 1/10/100/1000, 32 ch) seeded weights", 8
-    # stream 0 against the CPU oracle (whole sequence): the side workloads get a parity check of their own
-    import oracle
-    if a.workload == "diffdel":
+    # CPU leg of the side workloads (skipped with --no-cpu-baseline, like the headline's cpu_baseline): stream 0
+    # against the oracle over the whole sequence -- the oracle is the checker here, never the thing measured
+    ref0 = None
+    if not a.no_cpu_baseline:
+        import oracle
+    if a.no_cpu_baseline:
+        pass
+    elif a.workload == "diffdel":
         w_or = oracle.Weights.from_state_dict({k: v.numpy() for k, v in weights.load_state_dict(weights.W_DIFFDEL).items()})
         ref0 = oracle.diffdel_predict(w_or, x[:1, 0].cpu().numpy(), d[:1, 0].cpu().numpy(), model.max_delay)[0][0]
     else:
@@ -150,7 +155,7 @@ def side_workload(a):
                                  "traffic": None, "flop_per_sample": fl})(
             FLOP_PER_SAMPLE if a.workload == "diffdel" else 2 * (13 * 32 + 32 + 3 * (32 * 13 * 32 + 32 * 32) + 32)),
         "checks": {"deterministic": bool(torch.equal(y, y0)),
-                   "stream0_vs_oracle_max_abs": float(np.abs(y[0, 0].cpu().numpy() - ref0).max())}}))
+                   "stream0_vs_oracle_max_abs": None if ref0 is None else float(np.abs(y[0, 0].cpu().numpy() - ref0).max())}}))
 
 
 def main():
