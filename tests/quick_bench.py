@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Dev micro-benchmark: GRU kernel time at B x T (default 4096 x 8192) + max error vs the oracle.
-usage: [NTM_LIB_PATH=...] python tools/quick_bench.py [--variant mfma] [--B 4096] [--T 8192] [--iters 10]"""
+"""Dev micro-benchmark (lives under tests/ because it checks against the oracle): GRU kernel time at B x T (default 4096 x 8192) + max error vs the oracle.
+usage: [NTM_LIB_PATH=...] python tests/quick_bench.py [--variant mfma] [--B 4096] [--T 8192] [--iters 10]"""
 import argparse, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

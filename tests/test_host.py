@@ -93,6 +93,14 @@ def test_no_cpu_fallback():
                 text = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), fn
                 assert "ntm_oracle" not in text and "ntmo_" not in text, fn
+    # nor do the developer tools (anything that checks against the oracle lives under tests/); the only files outside
+    # tests/ that may touch oracle/ are __graft_entry__.py (smoke) and bench.py (its CPU legs)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tools")):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", "Makefile")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b|import ntm_amd, oracle", text, flags=re.M), fn
+                assert "ntm_oracle" not in text and "ntmo_" not in text, fn
 
 
 def test_shape_errors():
