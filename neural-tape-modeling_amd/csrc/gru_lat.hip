@@ -10,7 +10,7 @@
 //   exchange of the 3 x 4 partial sums through LDS, ONE s_barrier per step, fixed summation order
 //   every wave then evaluates the gates of all 64 units redundantly (lane u = unit u) and refreshes its private
 //   h copy -- no second barrier; the head y_t = w_o . h_t + b_o is a DPP wave reduction done by wave (t mod 4)
-//   one step later, while that step's partial sums travel through LDS.
+//   one step later, behind that step's barrier, in the shadow of the partial-sum reads.
 // x and y move in 256-sample tiles through LDS (coalesced global accesses).
 // Exact fp32 like the other exact kernels (different summation order: K split in four).
 #include "ntm_common.h"
@@ -86,19 +86,20 @@ __global__ __launch_bounds__(256) void gru_lat_kernel(GruArgs a)
     const float wir = a.w_ih[u] * SRZ, wiz = a.w_ih[kH + u] * SRZ, win = a.w_ih[2 * kH + u] * SN;
     const float br = (a.b_ih[u] + a.b_hh[u]) * SRZ, bz = (a.b_ih[kH + u] + a.b_hh[kH + u]) * SRZ;
     const float bin_ = a.b_ih[2 * kH + u] * SN, bhn = a.b_hh[2 * kH + u] * SN;
-    const float wo = a.w_o[u];
     const float bo = a.b_o ? a.b_o[0] : 0.0f;
     float hold = a.h_state ? a.h_state[s * kH + u] : 0.0f;
 
+    const float wo = a.w_o[u];
     hc[w][u] = hold;
     if (tid < T) xt[0][tid] = xs[tid];
     float xnext = (LT + tid < T) ? xs[LT + tid] : 0.0f;      // tile 1, parked in a register until mid-tile
     __syncthreads();
 
-    for (int64_t t = 0; t < T; ++t) {
-        const int ph = (int)(t & (LT - 1));
-        const int tb = (int)((t >> 8) & 1);
-        const int par = (int)(t & 1);
+    // one step; ph = t mod 256, tb = tile parity.  At step t the K quarter in hand is h_{t-1}, so the head partial
+    // computed here belongs to sample t-1: slot ph-1 of this tile, or slot 255 of the previous tile's buffer
+    // (at t = 0 that is a scratch write: buffer 1 is filled by samples 256.. long before it is flushed).
+    auto step = [&](const int ph, const int tb) {
+        const int par = ph & 1;
         // ---- this wave's quarter of h (uniform addresses: LDS broadcast) and the input sample ----
         // (v_readlane from the wave's own lanes 16w..16w+15 was tried instead of the private LDS copy: 16 VALU
         //  slots per step cost more than the 4 broadcast reads, 423 vs 405 ns at B = 1 and worse with more streams)
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void gru_lat_kernel(GruArgs a)
         const float x = xt[tb][ph];
         const f32x2 hq[8] = {{h0[0], h0[1]}, {h0[2], h0[3]}, {h1[0], h1[1]}, {h1[2], h1[3]},
                              {h2[0], h2[1]}, {h2[2], h2[3]}, {h3[0], h3[1]}, {h3[2], h3[3]}};
-        // ---- partial dot products (two packed accumulators per gate keep the chains short) ----
+        // ---- partial dot products (two packed accumulators per row keep the chains short) ----
         f32x2 ar0 = Wr[0] * hq[0], ar1 = Wr[1] * hq[1], az0 = Wz[0] * hq[0], az1 = Wz[1] * hq[1];
         f32x2 an0 = Wn[0] * hq[0], an1 = Wn[1] * hq[1];
 #pragma unroll
@@ -120,18 +121,19 @@ __global__ __launch_bounds__(256) void gru_lat_kernel(GruArgs a)
         part[par][0][u][w] = sr[0] + sr[1];
         part[par][1][u][w] = sz[0] + sz[1];
         part[par][2][u][w] = sn[0] + sn[1];
-        // while the exchange is in flight: the input terms, and the head of the PREVIOUS sample
-        // (y_{t-1} = w_o . h_{t-1} + b_o, `hold` still is h_{t-1}) on wave (t-1) mod 4 -- in the shadow of the
-        // LDS write latency every wave has to sit out before the barrier anyway
+        // input terms while the exchange is in flight
         const float cr = __builtin_fmaf(wir, x, br), cz = __builtin_fmaf(wiz, x, bz), gi = __builtin_fmaf(win, x, bin_);
-        if (t > 0 && (int)((t - 1) & 3) == w) {
-            const float yv = wave_sum_lane63(wo * hold) + bo;
-            if (u == 63) yt[(int)(((t - 1) >> 8) & 1)][(int)((t - 1) & (LT - 1))] = yv;
-        }
         __syncthreads();                                   // the step's only barrier
         const f32x4 qr = *(const f32x4 *)&part[par][0][u][0];
         const f32x4 qz = *(const f32x4 *)&part[par][1][u][0];
         const f32x4 qn = *(const f32x4 *)&part[par][2][u][0];
+        // head of the PREVIOUS sample (`hold` still is h_{t-1}) on one wave per step, as a DPP wave reduction issued
+        // right here: its dependent chain runs in the shadow of the three LDS reads above.  (Issued BEFORE the
+        // barrier it delayed the barrier for every wave: 405 instead of 362 ns per step.)
+        if ((ph & 3) == w) {
+            const float yv = wave_sum_lane63(wo * hold) + bo;
+            if (u == 63) { if (ph > 0) yt[tb][ph - 1] = yv; else yt[tb ^ 1][LT - 1] = yv; }
+        }
         const float pr_ = cr + ((qr[0] + qr[1]) + (qr[2] + qr[3]));
         const float pz_ = cz + ((qz[0] + qz[1]) + (qz[2] + qz[3]));
         const float gh = bhn + ((qn[0] + qn[1]) + (qn[2] + qn[3]));
@@ -143,16 +145,22 @@ __global__ __launch_bounds__(256) void gru_lat_kernel(GruArgs a)
         hold = __builtin_fmaf(z, hold - n, n);
         hc[w][u] = hold;                                   // private copy: read back by this wave only
         lds_fence_wave();
-        // ---- tile housekeeping (ordered by the per-step barrier) ----
-        if (ph == 2 && t >= LT) {                          // previous y tile is complete
-            const int64_t t0 = ((t >> 8) - 1) * LT;
-            ys[t0 + tid] = yt[tb ^ 1][tid];
-        }
-        if (ph == 128) {                                   // park the next x tile, fetch the one after
+    };
+
+    // tiles of 256 steps; the tile housekeeping sits between runs of steps, not inside the step
+    for (int64_t tile0 = 0; tile0 < T; tile0 += LT) {
+        const int ns = (int)((T - tile0) < LT ? (T - tile0) : LT);
+        const int tb = (int)((tile0 >> 8) & 1);
+        int ph = 0;
+        for (; ph < (ns < 3 ? ns : 3); ++ph) step(ph, tb);
+        if (ns > 2 && tile0 >= LT) ys[tile0 - LT + tid] = yt[tb ^ 1][tid];      // previous y tile is complete
+        for (; ph < (ns < 129 ? ns : 129); ++ph) step(ph, tb);
+        if (ns > 128) {                                     // park the next x tile, fetch the one after
             xt[tb ^ 1][tid] = xnext;
-            const int64_t nx = ((t >> 8) + 2) * LT + tid;
+            const int64_t nx = tile0 + 2 * LT + tid;
             xnext = nx < T ? xs[nx] : 0.0f;
         }
+        for (; ph < ns; ++ph) step(ph, tb);
     }
     if (T > 0 && w == 0) {                                  // head of the last sample
         const float yv = wave_sum_lane63(wo * hold) + bo;
