@@ -12,4 +12,4 @@ for B, block in [(1, 64), (16, 128), (64, 256), (256, 512)]:
         n = 500
         for _ in range(n): s.process(x)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-        print(f"B={B:4d} block={block:4d} graph={use_graph}: {dt*1e6:7.1f} us per block  (audio time of a block at 44.1 kHz: {block/44100*1e6:.0f} us, kernel ~{block*0.41:.0f} us)")
+        print(f"B={B:4d} block={block:4d} graph={use_graph}: {dt*1e6:7.1f} us per block  (audio time of a block at 44.1 kHz: {block/44100*1e6:.0f} us, kernel ~{block*0.34:.0f} us)")
