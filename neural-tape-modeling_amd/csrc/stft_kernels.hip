@@ -242,19 +242,15 @@ __global__ __launch_bounds__(256, (LOG2N <= 10 ? 2 : 1)) void stft_sums_kernel(S
         f2 v[P];
 #pragma unroll
         for (int q = 0; q < P; ++q) v[q] = (f2){wreg[q] * ry[q], wreg[q] * rt[q]};
-        if constexpr (LOG2N > 10) {
-            if (f0 + FSTEP < f_end) fetch(f + FSTEP);           // in flight during this frame's FFT
-        }
         // ---- Stockham autosort FFT, the frame slot's own LDS buffer between passes ----
         {
             PassTw<N, R0, 1> tw0;
             stockham_pass<N, R0, 1, true>(v, buf, tw0, sl);
         }
         stockham_pass<N, R1, R0, false>(v, buf, tw1, sl);
-        if constexpr (LOG2N <= 10) {
-            // n_fft <= 1024 runs two waves per SIMD (256 VGPRs): fetch late, when the big butterflies are done
-            if (f0 + FSTEP < f_end) fetch(f + FSTEP);
-        }
+        // the next frame's samples are fetched here, when the biggest butterflies are done and their registers are
+        // free again (fetching at the top of the frame cost n_fft = 2048 spills and 0.7 ms)
+        if (f0 + FSTEP < f_end) fetch(f + FSTEP);
         stockham_pass<N, R2, R0 * R1, false>(v, buf, tw2, sl);
         if constexpr (R3 > 1) stockham_pass<N, R3, R0 * R1 * R2, false>(v, buf, tw3, sl);
         wave_lds_fence();
