@@ -179,21 +179,38 @@ __global__ __launch_bounds__(256) void esr_dcpre_kernel(const float *y, const fl
 #pragma unroll
     for (int k = 1; k <= DCL; ++k) rp[k] = rp[k - 1] * R;
     __shared__ float wA[4], wBe[4], wBt[4], carry[2];
+    // the chunk is fetched with coalesced loads (lane-contiguous) and handed to the threads through LDS: a thread's
+    // 16 consecutive samples sit in a row of 17 floats (the pad keeps the row reads conflict-free).  Reading them
+    // straight from global memory (64-byte stride across lanes) cost 1.7 ms at 4096 x 65 536 instead of 0.6.
+    __shared__ float s_e[256 * (DCL + 1)], s_t[256 * (DCL + 1)];
     if (tid == 0) { carry[0] = 0.0f; carry[1] = 0.0f; }
     double se = 0.0, st = 0.0;
     for (int64_t c0 = skip; c0 < T; c0 += 256 * DCL) {
         __syncthreads();
         const float cin_e = carry[0], cin_t = carry[1];
+#pragma unroll
+        for (int i = 0; i < DCL; ++i) {
+            const int idx = i * 256 + tid;
+            const int64_t n = c0 + idx;
+            float tv = 0.0f, yv = 0.0f;
+            if (n < T) { tv = tb[n]; yv = yb[n]; }
+            s_t[(idx >> 4) * (DCL + 1) + (idx & 15)] = tv;
+            s_e[(idx >> 4) * (DCL + 1) + (idx & 15)] = tv - yv;
+        }
+        __syncthreads();
         const int64_t n0 = c0 + (int64_t)tid * DCL;
         float ue[DCL], ut[DCL];
         float pe = 0.0f, pt = 0.0f;
-        if (n0 > skip && n0 - 1 < T) { pt = tb[n0 - 1]; pe = pt - yb[n0 - 1]; }
+        if (n0 > skip && n0 - 1 < T) {
+            if (tid > 0) { pt = s_t[(tid - 1) * (DCL + 1) + DCL - 1]; pe = s_e[(tid - 1) * (DCL + 1) + DCL - 1]; }
+            else { pt = tb[n0 - 1]; pe = pt - yb[n0 - 1]; }
+        }
         float fe = 0.0f, ft = 0.0f;
 #pragma unroll
         for (int k = 0; k < DCL; ++k) {
             const int64_t n = n0 + k;
             float tv = 0.0f, ev = 0.0f;
-            if (n < T) { tv = tb[n]; ev = tv - yb[n]; } else { tv = pt; ev = pe; }   // past the end: u = 0
+            if (n < T) { tv = s_t[tid * (DCL + 1) + k]; ev = s_e[tid * (DCL + 1) + k]; } else { tv = pt; ev = pe; }   // past the end: u = 0
             fe = (ev - pe) + R * fe;
             ft = (tv - pt) + R * ft;
             pe = ev; pt = tv;
