@@ -17,11 +17,15 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend is None:
+        # NTM_DIST_BACKEND=gloo lets several ranks share one GPU (a dev box with a single MI355X): it exercises the
+        # N>1 control flow; real multi-GPU runs use nccl (= RCCL), one rank per GPU
+        backend = os.environ.get("NTM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if backend != "nccl" and torch.cuda.is_available() and torch.cuda.device_count() > 0:
+        local %= torch.cuda.device_count()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
