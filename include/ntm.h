@@ -186,6 +186,14 @@ int ntm_demodulate(const float *x, float *out, int C, int64_t N, const int64_t *
                    int64_t shift, double *scratch, void *stream);
 
 /*
+ * Record-head field of the reference's tape simulator, the stage in front of H_mag: I_rec = I + bias
+ * (code/tape.py:476-510; bias [N] fp64 is shared by all streams, NULL = bias disabled) and
+ * H = (gain * I_rec) / gap with gain = REC_N * REC_E, gap = REC_G (:512-514).  I, H: [B,N] fp64 device.
+ */
+int ntm_tape_record_field(const double *I, const double *bias, double *H, int64_t B, int64_t N, double gain,
+                          double gap, void *stream);
+
+/*
  * "Next" row N4: replaces Tape.H_mag, code/tape.py:516-551 (Jiles-Atherton hysteresis, RK4, fp64) of the
  * reference's white-box tape simulator.  H, M: [B,N] fp64 device, contiguous (oversampled rate);
  * state [B,3] fp64 device = (M_prev, H_prev, Hprime_prev), read and updated (zeros initially, :303-309);

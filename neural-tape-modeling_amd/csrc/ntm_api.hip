@@ -17,6 +17,8 @@ hipError_t launch_stft_sums(const float *y, const float *t, int64_t B, int64_t T
                             int win, float eps, int chunks, int mode, double *out, hipStream_t stream);
 hipError_t launch_demodulate(const float *x, float *out, int C, int64_t N, const int64_t *y_idx, int P, int64_t period,
                              int64_t shift, double *scratch, hipStream_t stream);
+hipError_t launch_tape_record_field(const double *I, const double *bias, double *H, int64_t B, int64_t N, double gain,
+                                    double gap, hipStream_t stream);
 hipError_t launch_tape_hmag(const double *H, double *M, int64_t B, int64_t N, double *state, double Ts, const double *par,
                             hipStream_t stream);
 hipError_t launch_tcn(const float *params, int L, int C, int K, const int *dil, const float *x, float *y, int64_t B,
@@ -228,6 +230,16 @@ int ntm_demodulate(const float *x, float *out, int C, int64_t N, const int64_t *
     if (x == out) return fail(NTM_EINVAL, "ntm_demodulate: out must not alias x");
     hipError_t e = ntm::launch_demodulate(x, out, C, N, y_idx, P, period, shift, scratch, (hipStream_t)stream);
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_demodulate");
+}
+
+int ntm_tape_record_field(const double *I, const double *bias, double *H, int64_t B, int64_t N, double gain, double gap,
+                          void *stream)
+{
+    if (B < 0 || N < 0 || !(gap != 0.0)) return fail(NTM_EINVAL, "ntm_tape_record_field: bad size or gap");
+    if (B == 0 || N == 0) return NTM_OK;
+    if (!I || !H) return fail(NTM_EINVAL, "ntm_tape_record_field: null pointer");
+    hipError_t e = ntm::launch_tape_record_field(I, bias, H, B, N, gain, gap, (hipStream_t)stream);
+    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_tape_record_field");
 }
 
 int ntm_tape_hmag(const double *H, double *M, int64_t B, int64_t N, double *state, double Ts, const double *params5,

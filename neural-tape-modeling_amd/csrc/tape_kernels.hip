@@ -109,6 +109,29 @@ __global__ __launch_bounds__(64) void tape_hmag_kernel(const double *H, double *
     if (valid) { state[3 * b] = Mp; state[3 * b + 1] = Hpv; state[3 * b + 2] = Hpp; }
 }
 
+// Record-head field of the reference's chain: I_rec = I_in + bias (code/tape.py:476-510), H = (N E I_rec) / G (:512-514),
+// one fp64 pass, same operation order (bit-identical to the reference's torch ops).  bias [N] is shared by the streams.
+__global__ __launch_bounds__(256) void tape_record_field_kernel(const double *I, const double *bias, double *H, int64_t B,
+                                                                int64_t N, double gain, double gap)
+{
+#pragma clang fp contract(off)
+    const int64_t total = B * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const double irec = bias ? I[i] + bias[i % N] : I[i];
+        H[i] = (gain * irec) / gap;
+    }
+}
+
+hipError_t launch_tape_record_field(const double *I, const double *bias, double *H, int64_t B, int64_t N, double gain,
+                                    double gap, hipStream_t stream)
+{
+    if (B == 0 || N == 0) return hipSuccess;
+    const int64_t total = B * N;
+    const unsigned grid = (unsigned)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+    hipLaunchKernelGGL(tape_record_field_kernel, dim3(grid), dim3(256), 0, stream, I, bias, H, B, N, gain, gap);
+    return hipGetLastError();
+}
+
 hipError_t launch_tape_hmag(const double *H, double *M, int64_t B, int64_t N, double *state, double Ts, const double *par,
                             hipStream_t stream)
 {

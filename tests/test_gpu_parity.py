@@ -882,3 +882,20 @@ def test_auto_splits_a_ragged_batch_between_the_two_kernels(ntm):
         mv = make_rnn(ntm, W_G, variant)
         mv.hidden = dev(h0[sl]).unsqueeze(0)
         assert np.array_equal(mv(dev(x[sl]).unsqueeze(1)).cpu().numpy()[:, 0], y[sl]), variant
+
+
+def test_g14_tape_record_field_and_chain(ntm):
+    """bias + H_rec on the device (ntm_tape_record_field) bit-identical to the reference's H over two stateful calls;
+    then the chain record_field -> H_mag against the oracle's magnetisation of the reference's own H."""
+    g = load("g14_tape_stages.npz")
+    sp = int(g["split"])
+    tp = ntm.TapeMagnetization(batch_size=2)
+    H1 = tp.record_field(dev(g["I_in"][:, :sp]))
+    H2 = tp.record_field(dev(g["I_in"][:, sp:]))
+    H = torch.cat([H1, H2], 1)
+    assert np.array_equal(H.cpu().numpy(), g["H"])
+    M = tp.H_mag(H[:, :3000]).cpu().numpy()
+    Mo, _ = oracle.tape_hmag(g["H"][:, :3000], None, tp.Ts_OS)
+    assert np.abs(M - Mo).max() < 1e-6 * tp.TAPE_Ms
+    tp2 = ntm.TapeMagnetization(batch_size=2, bias_enable=False)
+    assert np.array_equal(tp2.record_field(dev(g["I_in"][:, :100])).cpu().numpy(), (10.0 * g["I_in"][:, :100]) / 6e-6)

@@ -119,3 +119,17 @@ def test_shard_range_covers_everything():
             assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_g14_tape_stages_host_side():
+    """The stages of the reference's Tape around H_mag that run on the host or are plain gains (code/tape.py:466-510,
+    565-579): H_pre, the stateful bias waveform (start-up ramp, phase carried over two calls), H_play, H_post --
+    bit-identical to the reference's own output (golden g14)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g14_tape_stages.npz"))
+    tp = ntm_amd.TapeMagnetization(batch_size=2, device="cpu")
+    sp, N = int(g["split"]), g["V"].shape[1]
+    assert np.array_equal(tp.H_pre(g["V"]), g["I_in"])
+    b1, b2 = tp.bias_signal(sp), tp.bias_signal(N - sp)
+    assert np.array_equal(g["I_in"][:, :sp] + b1, g["I_rec"][:, :sp]) and np.array_equal(g["I_in"][:, sp:] + b2, g["I_rec"][:, sp:])
+    assert tp.bias_phase == float(g["bias_phase_end"]) and not tp.FLAG_STARTUP
+    assert np.array_equal(tp.H_play(g["M"]), g["V_play"]) and np.array_equal(tp.H_post(tp.H_play(g["M"])), g["V_out"])
