@@ -322,6 +322,29 @@ def test_full_size_cfg2_checksum(ntm):
     assert torch.equal(y, y[:1].expand_as(y))
 
 
+@pytest.mark.skipif(os.environ.get("NTM_SKIP_FULL") == "1", reason="full 4096x65536 pass skipped on request")
+def test_full_size_loss_pass_properties(ntm):
+    """The loss dict at BASELINE's full size (4096 x 65536) through size-independent properties: replicated streams
+    give replicated per-segment values; the oracle on one stream; a common gain leaves ESR, DCPreESR and the
+    spectral-convergence + log-magnitude loss unchanged (sums scale with the square of the gain)."""
+    B, T, skip = 4096, 65536, 1024
+    rng = np.random.default_rng(6)
+    t1 = (0.3 * rng.standard_normal((3, T))).astype(np.float32)
+    y1 = (t1 + 0.03 * rng.standard_normal((3, T))).astype(np.float32)
+    reps = -(-B // 3)
+    t = dev(np.tile(t1, (reps, 1))[:B]).unsqueeze(1)
+    y = dev(np.tile(y1, (reps, 1))[:B]).unsqueeze(1)
+    e, d = ntm.esr_sums(y, t, skip), ntm.esr_dcpre_sums(y, t, skip)
+    st = ntm.MRSTFTLoss().per_segment(y, t, skip)
+    for v in (e, d, st):
+        assert torch.equal(v[3:], v[:-3])                                   # streams 0,1,2 repeat over the batch
+    assert np.allclose(e[:3].cpu().numpy(), oracle.esr_sums(y1, t1, skip), rtol=1e-9)
+    assert np.allclose(d[:3].cpu().numpy(), oracle.esr_dcpre_sums(y1, t1, skip), rtol=2e-5)
+    assert np.allclose(st[:1].cpu().numpy(), oracle.mrstft_per_segment(y1[:1], t1[:1], skip), rtol=1e-4)
+    e2, st2 = ntm.esr_sums(2 * y, 2 * t, skip), ntm.MRSTFTLoss().per_segment(2 * y, 2 * t, skip)
+    assert torch.allclose(e2, 4 * e, rtol=1e-12) and torch.allclose(st2, st, rtol=1e-5)
+
+
 # ----------------------------------------------------------------------------- harness (test-model.py loss loop)
 def test_harness_compute_loss_gru_and_diffdel(ntm):
     """code/test-model.py:332-398 on in-memory segments: predict, cut INIT_LEN, per-segment ESR, mean."""
