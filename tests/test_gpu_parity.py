@@ -323,6 +323,23 @@ def test_full_size_cfg2_checksum(ntm):
 
 
 @pytest.mark.skipif(os.environ.get("NTM_SKIP_FULL") == "1", reason="full 4096x65536 pass skipped on request")
+def test_full_size_cfg3_diffdel(ntm):
+    """BASELINE cfg 3 at full size (DiffDelGRU, 4096 x 65536, D = 1847): two distinct (signal, trajectory) pairs tiled
+    over the batch must come back tiled (bit for bit, both outputs and both states), and equal the oracle."""
+    B, T = 4096, 65536
+    rng = np.random.default_rng(12)
+    n = np.arange(T)
+    x2 = rng.uniform(-0.5, 0.5, (2, T)).astype(np.float32)
+    d2 = (44100 * (0.0271 + np.array([[0.004], [0.0025]]) * np.sin(2 * np.pi * np.array([[1.3], [0.7]]) * n / 44100))).astype(np.float32)
+    m = ntm.harness.build_model(W_D, max_delay_seconds=0.0335)
+    y, pre = m.predict(dev(np.tile(x2, (B // 2, 1))).unsqueeze(1), dev(np.tile(d2, (B // 2, 1))).unsqueeze(1))
+    assert torch.equal(y[2:], y[:-2]) and torch.equal(pre[2:], pre[:-2])
+    assert torch.equal(m.hidden[0, 2:], m.hidden[0, :-2]) and torch.equal(m.diffdel.buffer[2:], m.diffdel.buffer[:-2])
+    yo, preo, _, _ = oracle.diffdel_predict(oracle_weights(W_D), x2, d2, m.max_delay)
+    assert np.abs(pre[:2, 0].cpu().numpy() - preo).max() < TOL and np.abs(y[:2, 0].cpu().numpy() - yo).max() < TOL
+
+
+@pytest.mark.skipif(os.environ.get("NTM_SKIP_FULL") == "1", reason="full 4096x65536 pass skipped on request")
 def test_full_size_loss_pass_properties(ntm):
     """The loss dict at BASELINE's full size (4096 x 65536) through size-independent properties: replicated streams
     give replicated per-segment values; the oracle on one stream; a common gain leaves ESR, DCPreESR and the
