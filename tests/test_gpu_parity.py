@@ -340,6 +340,22 @@ def test_full_size_cfg3_diffdel(ntm):
 
 
 @pytest.mark.skipif(os.environ.get("NTM_SKIP_FULL") == "1", reason="full 4096x65536 pass skipped on request")
+def test_full_size_cfg4_tcn(ntm):
+    """BASELINE cfg 4 at full size (TCN, 4096 x 65536, dilations 1/10/100/1000; 2 x 34 GB of activations in HBM): two
+    distinct streams tiled over the batch come back tiled bit for bit and equal the oracle."""
+    B, T = 4096, 65536
+    rng = np.random.default_rng(13)
+    x2 = rng.uniform(-0.8, 0.8, (2, T)).astype(np.float32)
+    m = ntm.TCN().to("cuda")
+    y = m(dev(np.tile(x2, (B // 2, 1))).unsqueeze(1))
+    assert torch.equal(y[2:], y[:-2])
+    yo = oracle.tcn_forward(m.packed_params().cpu().numpy(), len(m.dilations), m.channels, m.kernel_size, m.dilations, x2)
+    assert np.abs(y[:2, 0].cpu().numpy() - yo).max() < 2e-5
+    del y
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.skipif(os.environ.get("NTM_SKIP_FULL") == "1", reason="full 4096x65536 pass skipped on request")
 def test_full_size_loss_pass_properties(ntm):
     """The loss dict at BASELINE's full size (4096 x 65536) through size-independent properties: replicated streams
     give replicated per-segment values; the oracle on one stream; a common gain leaves ESR, DCPreESR and the
