@@ -955,3 +955,42 @@ def test_g14_tape_record_field_and_chain(ntm):
     assert np.abs(M - Mo).max() < 1e-6 * tp.TAPE_Ms
     tp2 = ntm.TapeMagnetization(batch_size=2, bias_enable=False)
     assert np.array_equal(tp2.record_field(dev(g["I_in"][:, :100])).cpu().numpy(), (10.0 * g["I_in"][:, :100]) / 6e-6)
+
+
+def test_concurrent_callers_on_two_streams(ntm):
+    """include/ntm.h promises re-entrant entry points (no global state, thread-local error text): two host threads,
+    each with its own model object and HIP stream, run different batches at the same time and get the numbers of
+    the serial runs; a failing call on one thread does not leak its message to the other."""
+    import threading
+    rng = np.random.default_rng(33)
+    xs = [rng.uniform(-0.5, 0.5, (B, 3000)).astype(np.float32) for B in (40, 1200)]     # low-latency and matrix-pipe kernels
+    want = []
+    for x in xs:
+        m = make_rnn(ntm, W_G, "auto")
+        want.append(m.predict(dev(x).unsqueeze(1)).clone())
+    got, errs = [None, None], [None, None]
+
+    def worker(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                m = make_rnn(ntm, W_G, "auto")
+                for _ in range(3):
+                    y = m.predict(dev(xs[i]).unsqueeze(1))
+                if i == 0:
+                    rc = ntm._lib.lib().ntm_stft_sums(None, None, 1, 100, 0, 1000, 1, 1, 1e-8, 1, None, None)
+                    assert rc != 0 and b"n_fft" in ntm._lib.lib().ntm_last_error()
+                else:
+                    assert b"n_fft" not in ntm._lib.lib().ntm_last_error()
+                s.synchronize()
+            got[i] = y
+        except Exception as e:          # noqa: BLE001
+            errs[i] = e
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert errs == [None, None], errs
+    assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
