@@ -10,12 +10,22 @@ The target is the output of the first (untimed) pass, so the ESR of every timed 
 exactly 0.0 -- a full-size determinism check -- and stream 0 carries the input of golden G6 so the
 result is also checked against the REFERENCE's own output on 65 536 samples.
 
-    python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+    python bench.py [--gpus N --steps K --warmup W] [--scaling weak|strong]
 Prints ONE JSON line on rank 0.
+
+N > 1 runs one process per GPU over RCCL.  Either the caller provides the ranks (`python -m torch.distributed.run
+--nproc-per-node N ... bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or --
+when WORLD_SIZE is NOT set -- `python bench.py --gpus N` starts them itself: the parent process, which never touches
+the GPU, spawns N fresh interpreters of this file with the rank environment, relays rank 0's JSON line and exits
+non-zero if any rank fails (spawn_ranks below).  `--scaling weak` (default): --batch segments PER GPU (N = 8 is
+BASELINE configs[4], 8 x 4096 = 32 768 segments); `--scaling strong`: --total-batch segments (default 32 768) split
+over the N ranks by distributed.shard_range.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -51,11 +61,12 @@ def synth_input(B, T, device, seed):
     return x.unsqueeze(1)
 
 
-def cpu_baseline(w_name, seconds_budget=12.0):
-    """Reference CPU path timed on this host: stock torch.nn.GRU + Linear on CPU (the modules the
-    reference builds at code/model.py:44-45) on a bounded sample of the workload (sized from a short
-    calibration run to take ~seconds_budget), on the cores this process may use; the C oracle
-    (OpenMP over streams) beside it."""
+def cpu_baseline(w_name):
+    """Reference CPU path timed on this host: stock torch.nn.GRU + Linear on CPU -- the modules the
+    reference builds at code/model.py:44-45 -- with the CHOWTAPE weights under inference_mode, on the two shapes the
+    survey names: 16 x 8192 (BASELINE configs[0], the reference's best CPU shape; `value`) and 64 x 8192; a bounded
+    sample of the workload (the full 4096 x 65 536 would take ~30 min), on the cores this process may use.  The C
+    oracle (OpenMP over streams) is timed beside it."""
     import oracle
     from ntm_amd import weights
     sd = weights.load_state_dict(w_name)
@@ -68,32 +79,36 @@ def cpu_baseline(w_name, seconds_budget=12.0):
     cores = max(1, min(cores, 32))              # tiny per-step GEMMs do not scale past a few dozen threads
     torch.set_num_threads(cores)
     f = oracle.torch_gru_port(w)
-    B = 16                                      # the reference's best CPU shape
-    h0 = np.repeat(oracle.warm_state(w), B, 0)
-    xc = rng.uniform(-0.5, 0.5, (B, 512)).astype(np.float32)
-    f(xc, h0)                                   # thread-pool warm-up
-    t0 = time.perf_counter()
-    f(xc, h0)
-    rate = xc.size / (time.perf_counter() - t0)
-    T = int(min(65536, max(2048, 2 ** int(np.log2(max(rate * seconds_budget / B, 2048))))))
-    x = rng.uniform(-0.5, 0.5, (B, T)).astype(np.float32)
-    t0 = time.perf_counter()
-    f(x, h0)
-    dt = time.perf_counter() - t0
-    res = {"value": x.size / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-           "sample": f"{B}x{T} samples of the same workload, torch.nn.GRU+Linear on CPU, {cores} threads"}
-    xo = rng.uniform(-0.5, 0.5, (2 * cores, 4096)).astype(np.float32)
+    f(rng.uniform(-0.5, 0.5, (16, 512)).astype(np.float32), np.repeat(oracle.warm_state(w), 16, 0))   # thread-pool warm-up
+    shapes = {}
+    for B, T, reps in ((16, 8192, 3), (64, 8192, 1)):
+        h0 = np.repeat(oracle.warm_state(w), B, 0)
+        x = rng.uniform(-0.5, 0.5, (B, T)).astype(np.float32)
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            f(x, h0)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        shapes[f"{B}x{T}"] = {"value": x.size / best, "seconds": best, "repetitions": reps}
+    res = {"value": shapes["16x8192"]["value"], "unit": "samples/s", "cores": cores, "kind": "port",
+           "sample": f"16 x 8192 samples (BASELINE configs[0] shape) of the same workload, best of 3, torch.nn.GRU+Linear "
+                     f"on CPU under inference_mode, {cores} threads; 64 x 8192 beside it",
+           "shapes": shapes}
+    xo = rng.uniform(-0.5, 0.5, (2 * cores, 8192)).astype(np.float32)
     t0 = time.perf_counter()
     oracle.gru_forward(w, xo, threads=cores)
     dt = time.perf_counter() - t0
     res["oracle_c"] = {"value": xo.size / dt, "unit": "samples/s", "cores": cores,
-                       "sample": f"{xo.shape[0]}x4096 samples, C restatement, OpenMP over streams"}
+                       "sample": f"{xo.shape[0]}x8192 samples, C restatement, OpenMP over streams"}
     return res
 
 
 def side_workload(a):
     """BASELINE configs[2] (DiffDelGRU-HS[64], CHOWTAPE_WOWFLUTTER weights) and configs[3] (TCN contrast
-    point) at the same batch; single GPU, not the headline metric."""
+    point) at the same batch; single GPU, not the headline metric.  Like the headline line, the JSON carries the
+    roofline of the dominant kernel with its event-timed launch duration (`roofline.kernel`, `kernel_ms`); for the
+    DiffDelGRU step the HBM roofline of the delay-line pass (K2) sits beside it as `roofline.delay_line`."""
     import ntm_amd
     from ntm_amd import weights
     assert torch.cuda.is_available()
@@ -101,6 +116,7 @@ def side_workload(a):
     B, T = a.batch, a.samples
     x = synth_input(B, T, dev, seed=1234)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    kev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     if a.workload == "diffdel":
         model = ntm_amd.harness.build_model(weights.W_DIFFDEL, max_delay_seconds=0.0335, device=dev)   # D = 1847
         g = torch.Generator(device=dev); g.manual_seed(77)
@@ -114,48 +130,148 @@ def side_workload(a):
             d[sl] = FS * (0.0271 + amp[sl] * torch.sin(2 * np.pi * wv[sl] * n / FS + psi[sl])
                           + 0.0005 * torch.sin(2 * np.pi * 23 * n / FS))
         d = d.clamp_(0, model.max_delay).unsqueeze(1)
-        run = lambda: model.predict(x, d)[0]                                 # noqa: E731
+        run = lambda: model.predict(x, d, _events=kev)[0]                    # noqa: E731
         name, bytes_per_sample = "DiffDelGRU-HS[64] CHOWTAPE_WOWFLUTTER weights, D=1847", 16
     else:
         model = ntm_amd.TCN().to(dev)
-        run = lambda: model(x)                                               # noqa: E731
+
+        def run():
+            kev[0].record(); y = model(x); kev[1].record()
+            return y
         name, bytes_per_sample = "TCN 4x(k13, dil 1/10/100/1000, 32 ch) seeded weights", 8
-    # CPU leg of the side workloads (skipped with --no-cpu-baseline, like the headline's cpu_baseline): stream 0
-    # against the oracle over the whole sequence -- the oracle is the checker here, never the thing measured
-    ref0 = None
+    # CPU leg of the side workloads (skipped with --no-cpu-baseline, like the headline's cpu_baseline): scattered
+    # streams against the oracle over the whole sequence -- the oracle is the checker here, never the thing measured
+    ref, rows = None, [r for r in (0, 17, B // 2 + 1, B - 1) if r < B]
     if not a.no_cpu_baseline:
         import oracle
-    if a.no_cpu_baseline:
-        pass
-    elif a.workload == "diffdel":
-        w_or = oracle.Weights.from_state_dict({k: v.numpy() for k, v in weights.load_state_dict(weights.W_DIFFDEL).items()})
-        ref0 = oracle.diffdel_predict(w_or, x[:1, 0].cpu().numpy(), d[:1, 0].cpu().numpy(), model.max_delay)[0][0]
-    else:
-        ref0 = oracle.tcn_forward(model.packed_params().cpu().numpy(), len(model.dilations), model.channels,
-                                  model.kernel_size, model.dilations, x[:1, 0].cpu().numpy())[0]
+        xs = x[rows, 0].cpu().numpy()
+        if a.workload == "diffdel":
+            w_or = oracle.Weights.from_state_dict({k: v.numpy() for k, v in weights.load_state_dict(weights.W_DIFFDEL).items()})
+            ref = oracle.diffdel_predict(w_or, xs, d[rows, 0].cpu().numpy(), model.max_delay)[0]
+        else:
+            ref = oracle.tcn_forward(model.packed_params().cpu().numpy(), len(model.dilations), model.channels,
+                                     model.kernel_size, model.dilations, xs)
     for _ in range(max(a.warmup, 1)):
         y0 = run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ms = []
+    ms, k1, k2 = [], [], []
     for _ in range(a.steps):
         ev0.record(); y = run(); ev1.record(); torch.cuda.synchronize()
         ms.append(ev0.elapsed_time(ev1))
+        k1.append(kev[0].elapsed_time(kev[1]))
+        if a.workload == "diffdel":
+            k2.append(kev[1].elapsed_time(kev[2]))
     elapsed = time.perf_counter() - t0
+    # dominant kernel: the GRU launch (DiffDelGRU: the delay line adds 3 flop/sample) resp. the TCN forward
+    # (43 520 FMA per sample; its five launches cannot be separated by events: profiles/ has the rocprofv3 split)
+    fl = FLOP_PER_SAMPLE if a.workload == "diffdel" else 2 * (13 * 32 + 32 + 3 * (32 * 13 * 32 + 32 * 32) + 32)
+    ksec = float(np.mean(k1)) * 1e-3
+    roof = {"bound": "mfma", "achieved": fl * B * T / ksec / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+            "frac": fl * B * T / ksec / 1e12 / PEAK_FP32_TFLOPS, "traffic": None, "flop_per_sample": fl,
+            "kernel": "gru_mfma2_kernel" if a.workload == "diffdel" else "tcn_forward (first block + 3 MFMA blocks, output conv fused)",
+            "kernel_ms": 1e3 * ksec}
+    if a.workload == "diffdel":
+        # K2 as a separate streaming pass: pre_d and d read once, y written once = 12 algorithmic bytes per sample
+        # (the two gathered taps come from pre_d, i.e. from the same bytes); the carried buffer adds 8 D bytes per stream
+        dsec = float(np.mean(k2)) * 1e-3
+        alg = 12.0 * B * T + 8.0 * B * model.diffdel.max_delay
+        roof["delay_line"] = {"bound": "hbm", "kernel": "delay_apply_kernel + delay_update_kernel", "kernel_ms": 1e3 * dsec,
+                              "achieved": alg / dsec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                              "frac": alg / dsec / 1e9 / PEAK_HBM_GBS, "bytes_per_sample": 12,
+                              "frac_at_16B_per_sample": 16.0 * B * T / dsec / 1e9 / PEAK_HBM_GBS}
     print(json.dumps({
         "metric": f"audio samples/sec (44.1 kHz) {a.workload}, batch={B}x{T}", "value": B * T * a.steps / elapsed,
         "unit": "samples/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{name}, {B} segments x {T} samples fp32"},
         "device_ms_per_step": float(np.mean(ms)), "bytes_per_sample": bytes_per_sample,
-        # whole-step roofline (several kernels per step): algorithmic flops over the device time of a step against the
-        # fp32 peak; DiffDelGRU = the GRU flops (the delay line adds 3 flop/sample), TCN = 43 520 FMA per sample
-        "roofline": (lambda fl: {"bound": "mfma", "achieved": fl * B * T / (np.mean(ms) * 1e-3) / 1e12, "peak": PEAK_FP32_TFLOPS,
-                                 "unit": "TFLOP/s", "frac": fl * B * T / (np.mean(ms) * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
-                                 "traffic": None, "flop_per_sample": fl})(
-            FLOP_PER_SAMPLE if a.workload == "diffdel" else 2 * (13 * 32 + 32 + 3 * (32 * 13 * 32 + 32 * 32) + 32)),
-        "checks": {"deterministic": bool(torch.equal(y, y0)),
-                   "stream0_vs_oracle_max_abs": None if ref0 is None else float(np.abs(y[0, 0].cpu().numpy() - ref0).max())}}))
+        "roofline": roof,
+        "checks": {"deterministic": bool(torch.equal(y, y0)), "streams_checked": rows if ref is not None else [],
+                   "vs_oracle_max_abs": None if ref is None else float(np.abs(y[rows, 0].cpu().numpy() - ref).max())}}))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N fresh interpreters of this file, one per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relay rank 0's stdout (the JSON line), and
+    return non-zero if any rank fails (the others are then terminated by PID so nobody waits in a collective).
+    This parent never initialises HIP (torch.cuda.device_count() does not), and no process that has is ever
+    re-exec'd: the children are new processes."""
+    backend = os.environ.get("NTM_DIST_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < n and "--launch-check" not in argv:
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs for the RCCL run, found {have} "
+              f"(NTM_DIST_BACKEND=gloo shares one GPU between ranks for a control-flow check)", file=sys.stderr)
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    failed = None
+    out0 = ""
+    try:
+        live = set(range(n))
+        while live and failed is None:
+            for r in sorted(live):
+                rc = procs[r].poll() if r else None
+                if r == 0:
+                    try:                                       # drain rank 0's pipe while waiting for it
+                        out0_, _ = procs[0].communicate(timeout=0.2)
+                        out0 += out0_ or ""
+                        rc = procs[0].returncode
+                    except subprocess.TimeoutExpired:
+                        rc = None
+                if rc is not None:
+                    live.discard(r)
+                    if rc != 0:
+                        failed = (r, rc)
+                        break
+            if live and failed is None:
+                time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if failed is not None:
+        print(f"bench.py: rank {failed[0]} exited with status {failed[1]}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def launch_check(a):
+    """--launch-check: the N-rank control flow of this file without the data path (runs on CPU over gloo in the
+    `not gpu` tests): rank environment -> process group -> shard ranges -> one SUM all-reduce -> rank 0 prints."""
+    from ntm_amd import distributed as D
+    rank, world, local = D.init_from_env("gloo")
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    total = a.total_batch if a.scaling == "strong" else a.batch * world
+    lo, hi = D.shard_range(total, rank, world) if a.scaling == "strong" else (rank * a.batch, (rank + 1) * a.batch)
+    v = torch.tensor([float(hi - lo), float(rank), 1.0], dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(v)
+    D.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "world": world, "segments_total": int(v[0]), "rank_sum": int(v[1]),
+                          "ranks": int(v[2]), "scaling": a.scaling}))
+    if a.fail_rank == rank:
+        sys.exit(3)
 
 
 def main():
@@ -163,14 +279,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="segments per GPU")
+    ap.add_argument("--batch", type=int, default=4096, help="segments per GPU (weak scaling)")
     ap.add_argument("--samples", type=int, default=65536, help="samples per segment")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch segments per GPU (N = 8: BASELINE configs[4]); strong: --total-batch segments over all GPUs")
+    ap.add_argument("--total-batch", type=int, default=32768, help="segments of the whole job under --scaling strong")
     ap.add_argument("--variant", default="auto", choices=["auto", "mfma2", "mfma", "valu", "f16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the opt-in f16x3 kernel leg")
     ap.add_argument("--workload", default="gru", choices=["gru", "diffdel", "tcn"],
                     help="gru = BASELINE configs[1] (the headline metric); diffdel = configs[2]; tcn = configs[3]")
+    ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     a = ap.parse_args()
+
+    # N > 1 and nobody gave us a rank: this process becomes the launcher (before anything touches the GPU)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus, sys.argv[1:]))
+    if a.launch_check:
+        return launch_check(a)
 
     import ntm_amd
     from ntm_amd import distributed as D, weights
@@ -188,11 +315,27 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    B, T = a.batch, a.samples
+    T = a.samples
+    if a.scaling == "strong":
+        lo, hi = D.shard_range(a.total_batch, rank, world)
+        B, first_segment = hi - lo, lo
+    else:
+        B, first_segment = a.batch, rank * a.batch
+    total_segments = a.total_batch if a.scaling == "strong" else a.batch * world
+    # which device each rank drives, gathered over the job's own backend (shows that RCCL saw N ranks on N GPUs)
+    props = torch.cuda.get_device_properties(local)
+    mine = torch.tensor([rank, local, int(getattr(props, "pci_bus_id", -1)), int(getattr(props, "pci_device_id", -1))],
+                        dtype=torch.int64, device=dev)
+    if world > 1:
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+    else:
+        allr = [mine]
+    rank_devices = [{"rank": int(v[0]), "device": int(v[1]), "pci_bus": int(v[2]), "pci_device": int(v[3])} for v in allr]
 
     model = ntm_amd.harness.build_model(weights.W_GRU, device=dev)
     model.kernel_variant = a.variant
-    x = synth_input(B, T, dev, seed=1234 + rank)
+    x = synth_input(B, T, dev, seed=1234 + first_segment // 4096)    # weak: one seed per 4096-segment block
     gold = None
     if rank == 0 and T == 65536:
         gold = np.load(os.path.join(ROOT, "tests", "golden", "g6_long_65536.npz"))
@@ -256,7 +399,7 @@ def main():
     # ---- opt-in kernel variant, reported beside the headline (never part of `value`): the f16x3 GEMV
     #      engine, checked over the whole batch against the exact-fp32 pass
     extra = {}
-    if a.variant in ("auto", "mfma2") and not a.no_extra:
+    if a.variant in ("auto", "mfma2") and not a.no_extra and world == 1:
         model.kernel_variant = "f16x3"
         ms2 = []
         for i in range(2 + 5):
@@ -301,9 +444,12 @@ def main():
         ev0.record(); cp.copy_(x); ev1.record(); torch.cuda.synchronize()
     hbm_copy_gbs = 2.0 * x.numel() * 4 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
     del cp
+    if world > 1:
+        D.barrier()
+        torch.distributed.destroy_process_group()
     if rank != 0:
         return
-    total_samples = float(B) * T * world * a.steps
+    total_samples = float(total_segments) * T * a.steps
     kern_s = float(np.mean(kern_ms)) / 1e3
     # exact-fp32 kernels: algorithmic flops against the fp32 matrix peak.  --variant f16x3 (opt-in): the MFMA
     # flops it actually executes (three fp16 products per W.h term) against the dense fp16 MFMA peak.
@@ -322,24 +468,28 @@ def main():
                                                    ((gold["y"][0, 0][INIT_LEN:] ** 2).mean() + ESR_EPS))
     # HBM bytes per launch from the PMC counters (collected in separate rocprofv3 --pmc passes, gfx950
     # FETCH_SIZE correction applied; see profiles/*pmc_traffic*.json) -- only for the matching workload
-    traffic = None
+    traffic, traffic_source = None, None
     if (B, T) == (4096, 65536) and a.variant in ("auto", "mfma2"):
         import glob
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic_mfma2*.json")))
         if files:
             traffic = json.load(open(files[-1]))["hbm_bytes_per_launch_corrected"]
+            traffic_source = "profiles/" + os.path.basename(files[-1]) + " (rocprofv3 --pmc passes of this command; not re-measured in this run)"
     out = {
         "metric": "audio samples/sec (44.1 kHz) GRU-HS[64], batch=4096x65536",
         "value": total_samples / elapsed, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-        "config": {"workload": f"GRU-HS[64] CHOWTAPE weights, {B} segments x {T} samples fp32 per GPU, "
+        "scaling": a.scaling, "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": f"GRU-HS[64] CHOWTAPE weights, {total_segments} segments x {T} samples fp32 "
+                               f"({B} on rank 0), "
                                f"predict (warm-start + persistent GRU kernel) + ESR sums on a side stream under the next step's launch + one all-reduce of the per-step loss scalars",
-                   "segments_per_gpu": B, "samples_per_segment": T, "kernel": a.variant,
+                   "segments_total": total_segments, "segments_rank0": B, "samples_per_segment": T, "kernel": a.variant,
                    "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
+        "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else "none (single process)",
+        "rccl_ranks": world if backend == "nccl" else 0, "ranks": world, "rank_devices": rank_devices,
         "realtime_factor": total_samples / elapsed / FS,
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": peak_tflops, "unit": "TFLOP/s",
-                     "frac": tflops / peak_tflops, "traffic": traffic,
+                     "frac": tflops / peak_tflops, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": {"auto": "gru_mfma2_kernel", "mfma2": "gru_mfma2_kernel", "mfma": "gru_mfma_kernel",
                                 "valu": "gru_valu_kernel", "f16x3": "gru_mfma2_kernel<f16x3>"}[a.variant],
                      "kernel_ms": 1e3 * kern_s, "flop_per_sample": flop_per_sample,

@@ -32,7 +32,12 @@ extern "C" {
 #define NTM_EHIP (-2)    /* HIP runtime error (launch failed, no device)               */
 #define NTM_EDELAY (-3)  /* reserved for host-side delay-range checks                  */
 
-#define NTM_HIDDEN 64 /* the only hidden size compiled (every shipped checkpoint is HS[64]) */
+#define NTM_ABI_VERSION 2 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag */
+
+#define NTM_HIDDEN 64 /* hidden size of every shipped checkpoint (HS[64]): matrix-pipe and low-latency kernels.
+                         H = 8, 16, 32 (the reference's constructor default is 8, code/model.py:22; its training
+                         default 16, code/train.py:50) run on one wave-per-64/H-streams kernel, any variant
+                         among AUTO / LAT / VALU.                                                               */
 
 /* GRU kernel variants for ntm_gru_forward_ex:                              */
 #define NTM_GRU_AUTO 0  /* NTM_GRU_MFMA2, or NTM_GRU_LAT when B <= NTM_GRU_LAT_MAX_B         */
@@ -60,7 +65,7 @@ const char *ntm_last_error(void);
  *   b_ih [3H]      GRU.bias_ih_l0               b_hh [3H]     GRU.bias_hh_l0
  *   w_o  [H]       output.weight (1,H)          b_o  [1] or NULL   output.bias
  * x [B,T] (stride x_stride_b) -> y [B,T] (stride y_stride_b).
- * h_state [B,H] is read as h_0 and overwritten with h_T (the reference's self.hidden);
+ * H in {8, 16, 32, 64}.  h_state [B,H] is read as h_0 and overwritten with h_T (the reference's self.hidden);
  * NULL means h_0 = 0 and h_T is discarded.  B == 0 or T == 0 is a successful no-op.
  */
 int ntm_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
@@ -100,16 +105,16 @@ int ntm_debug_transpose4(const float *in, float *out, void *stream);
  * x, d, y: [B,T] contiguous (stride T); d in SAMPLES.  dl_state [B,D] is the reference's
  * `self.buffer` (oldest sample first) and is updated in place to cat(buffer[T:], x[-D:]).
  * warmup != 0: y = x, only the buffer is updated (code/model.py:288-292).
- * y must not alias x.  `scratch` must hold B*min(T,D)... see ntm_delay_scratch_floats().
- * err_flag (device int32, may be NULL): set to 1 if any d > D -- the reference raises
- * AssertionError there (code/model.py:284); the caller checks it after synchronising.
+ * y must not alias x.  One pass over the audio: d is read once, there is no separate range check.
+ * err_flag (device int32, caller-owned, may be NULL): raised to 1 if any d > D (or NaN) -- the reference raises
+ * AssertionError there (code/model.py:284) before touching its state; here y of the violating call is
+ * unspecified and dl_state is left untouched.  The flag is STICKY: while it is non-zero every later call that is
+ * given the same flag is a no-op (the state stays frozen at the last good call), so a caller that streams many
+ * chunks may look at it once at the end instead of synchronising per chunk, and clears it (hipMemsetAsync)
+ * when it re-initialises the state.
  */
 int ntm_delay_forward(const float *x, const float *d, float *y, int64_t B, int64_t T,
-                      float *dl_state, int D, int warmup, float *scratch, int32_t *err_flag,
-                      void *stream);
-
-/* Number of floats ntm_delay_forward needs in `scratch` for (B,T,D). */
-int64_t ntm_delay_scratch_floats(int64_t B, int64_t T, int D);
+                      float *dl_state, int D, int warmup, int32_t *err_flag, void *stream);
 
 /*
  * Replaces DiffDelRNN.forward(x, del_traj, warmup), code/model.py:393-424:
@@ -119,17 +124,20 @@ int64_t ntm_delay_scratch_floats(int64_t B, int64_t T, int D);
 int ntm_diffdel_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih,
                             const float *b_hh, const float *w_o, int H, const float *x,
                             const float *d, float *y, float *pre_d, int64_t B, int64_t T,
-                            float *h_state, float *dl_state, int D, int warmup, float *scratch,
-                            int32_t *err_flag, void *stream);
+                            float *h_state, float *dl_state, int D, int warmup, int32_t *err_flag,
+                            void *stream);
 
 /*
  * Per-stream sums for the ESR loss that follows the path in code/test-model.py:250-254,386-388
- * (CoreAudioML ESRLoss, un-vendored): over samples [skip, T) of stream b
- *   out[2b] = sum (t - y)^2      out[2b+1] = sum t^2        (fp64, device)
+ * (CoreAudioML ESRLoss, un-vendored): over samples [skip, T) of stream b, split over `splits` workgroups p:
+ *   out[(b*splits + p)*2 + 0] = partial sum (t - y)^2      out[(b*splits + p)*2 + 1] = partial sum t^2   (fp64, device)
+ * The caller adds the `splits` rows of a stream in index order: no atomics anywhere, the sums are bit-reproducible
+ * from run to run for every B.  ntm_esr_splits() gives the split count that fills the device (1 for B >= 2048).
  * y, t: [B,T] contiguous.
  */
-int ntm_esr_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, double *out,
+int ntm_esr_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int splits, double *out,
                  void *stream);
+int ntm_esr_splits(int64_t B, int64_t T, int64_t skip);
 
 /*
  * As ntm_esr_sums, on the DC-blocked signals: both y and t pass H(z) = (1 - z^-1)/(1 - R z^-1) (zero state

@@ -26,11 +26,11 @@ _SIGNATURES = {
     "ntm_debug_gru_stamps": (_int, [_vp] * 6 + [_vp, _vp, _i64, _i64, _vp, _vp, _int, _vp]),
     "ntm_debug_transpose4": (_int, [_vp, _vp, _vp]),
     "ntm_debug_gru_ablate": (_int, [_vp] * 6 + [_vp, _vp, _i64, _i64, _vp, _int, _vp]),
-    "ntm_delay_forward": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _int, _int, _vp, _vp, _vp]),
-    "ntm_delay_scratch_floats": (_i64, [_i64, _i64, _int]),
+    "ntm_delay_forward": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _int, _int, _vp, _vp]),
     "ntm_diffdel_gru_forward": (_int, [_vp] * 5 + [_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _int,
-                                                   _vp, _vp, _vp]),
-    "ntm_esr_sums": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp]),
+                                                   _vp, _vp]),
+    "ntm_esr_sums": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp, _vp]),
+    "ntm_esr_splits": (_int, [_i64, _i64, _i64]),
     "ntm_esr_dcpre_sums": (_int, [_vp, _vp, _i64, _i64, _i64, ctypes.c_float, _vp, _vp]),
     "ntm_spec_sums": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _int, _int, ctypes.c_float, _int, _vp, _vp]),
     "ntm_stft_sums": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _int, _int, ctypes.c_float, _int, _vp, _vp]),
@@ -43,6 +43,8 @@ _SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 2          # include/ntm.h NTM_ABI_VERSION this binding was written against
+HIDDEN_SIZES = (8, 16, 32, 64)
 
 
 class NtmError(RuntimeError):
@@ -65,6 +67,8 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
+        if handle.ntm_abi_version() != ABI_VERSION:
+            raise NtmError(f"{LIB_PATH} has ABI version {handle.ntm_abi_version()}, this binding needs {ABI_VERSION}: rebuild it")
         _lib = handle
     return _lib
 

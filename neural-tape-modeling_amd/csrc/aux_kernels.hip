@@ -9,14 +9,15 @@ namespace ntm {
 //   y[n] = sum_{m in {k+1,k}, 0<=m<=D} relu(1-|m-d[n]|) * xpad[n-m],  k = floor(d[n])
 //   xpad[i<0] = buffer[D+i].  Products and the sum are individually rounded (no fma contraction)
 //   in the reference's order, so the result is bit-identical to the O(T*D) unfold formulation.
+// Two launches per call, ONE pass over the audio:
+//   delay_apply_kernel   reads d and the taps, writes y, and raises the error flag where d > D (the reference's
+//                        assert, code/model.py:284) -- d is read once, there is no separate range-check pass;
+//   delay_update_kernel  buffer <- cat(buffer[T:], x[-D:]) in place (B x D floats), skipped when the flag is up,
+//                        so the carried state stays untouched exactly when the reference would have raised.
+// The flag is STICKY and caller-owned: once it is non-zero every later K2 launch on it is a no-op (state frozen at
+// the last good call) until the caller clears it -- the host checks it when it wants to (once per predict), not per call.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void delay_check_kernel(const float *d, int64_t n, float Dmax, int32_t *flag)
-{
-    int bad = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        bad |= (d[i] > Dmax) ? 1 : 0;
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
-}
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
 
 // one output sample: y[n] = w_b x[n-k-1] + w_a x[n-k] with the reference's tap order and rounding
 __device__ __forceinline__ float delay_sample(const float *xb, const float *bb, int D, int64_t n, float dn)
@@ -38,83 +39,115 @@ __device__ __forceinline__ float delay_sample(const float *xb, const float *bb, 
     return acc;
 }
 
-// thread -> 4 consecutive samples: d is read and y written with 16-byte accesses when the rows allow it
-// (HBM-bound pass: 12 B/sample + the two gathered taps, which hit L2)
+// the same sample when both taps are known to lie inside x and inside [0, D]: xa = x[n-k], xb1 = x[n-k-1]
+__device__ __forceinline__ float delay_sample_fast(float dn, float kf, float xa, float xb1)
+{
+#pragma clang fp contract(off)
+    float acc = 0.0f;
+    const float wb = 1.0f - fabsf((kf + 1.0f) - dn);
+    if (wb > 0.0f) { const float prod = wb * xb1; acc = acc + prod; }
+    const float wa = 1.0f - fabsf(kf - dn);
+    if (wa > 0.0f) { const float prod = wa * xa; acc = acc + prod; }
+    return acc;
+}
+
+// thread -> DV consecutive samples (DV = 8: two 16-byte loads of d, two 16-byte stores of y).  Fast path, taken when
+// the DV delays of the thread share one integer part k with 0 <= k < D and the window lies inside x: the DV + 1
+// samples x[n0-k-1 .. n0+DV-1-k] the taps need are contiguous -> two 16-byte loads at 4-byte alignment + one dword
+// instead of 2 DV scalar gathers.  Everything else (k changes inside the thread's run, history taps, k = D, d < 0,
+// NaN) goes through delay_sample().  HBM-bound pass: 12 B/sample (d, x once, y).
+constexpr int DV = 8;
 __global__ __launch_bounds__(256) void delay_apply_kernel(const float *x, const float *d, float *y, int64_t B,
                                                           int64_t T, const float *buf, int D, int warmup,
-                                                          const int32_t *flag)
+                                                          int32_t *flag)
 {
-    if (flag && *flag) return;
-    const int64_t b = blockIdx.x;
+    if (flag && *flag) return;                       // sticky: an earlier violation froze this state
+    const int64_t tiles = (T + 256 * DV - 1) / (256 * DV);
+    const int64_t b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
     const float *xb = x + b * T, *db = d + b * T, *bb = buf + b * (int64_t)D;
     float *yb = y + b * T;
-    const bool vec = ((T & 3) == 0) && (((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(y) |
-                                          reinterpret_cast<uintptr_t>(x)) & 15) == 0);
-    for (int64_t n0 = 4 * ((int64_t)blockIdx.y * blockDim.x + threadIdx.x); n0 < T; n0 += 4 * (int64_t)gridDim.y * blockDim.x) {
-        if (vec) {                                   // n0 + 3 < T because T is a multiple of 4
-            if (warmup) { *(f32x4 *)(yb + n0) = *(const f32x4 *)(xb + n0); continue; }
-            const f32x4 dv = *(const f32x4 *)(db + n0);
-            f32x4 out;
+    const float Dmax = (float)D;
+    const bool vec = ((T & 3) == 0) && (((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
+    const int64_t n0 = (tile * 256 + threadIdx.x) * DV;
+    int bad = 0;
+    if (n0 + DV <= T && vec) {
+        const f32x4 d0 = *(const f32x4 *)(db + n0), d1 = *(const f32x4 *)(db + n0 + 4);
+        float dv[DV] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+        const float kf = floorf(dv[0]);
+        bool same = kf >= 0.0f && kf < Dmax && (n0 - (int64_t)kf - 1) >= 0;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) out[c] = delay_sample(xb, bb, D, n0 + c, dv[c]);
-            *(f32x4 *)(yb + n0) = out;
+        for (int c = 0; c < DV; ++c) {
+            bad |= !(dv[c] <= Dmax);                 // also true for NaN, like `max_delay >= max(dt)` failing
+            same = same && (floorf(dv[c]) == kf);
+        }
+        float out[DV];
+        if (warmup) {
+            const f32x4u x0 = *(const f32x4u *)(xb + n0), x1 = *(const f32x4u *)(xb + n0 + 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { out[c] = x0[c]; out[4 + c] = x1[c]; }
+        } else if (same) {
+            const float *w0 = xb + (n0 - (int64_t)kf - 1);
+            const f32x4u x0 = *(const f32x4u *)w0, x1 = *(const f32x4u *)(w0 + 4);
+            const float win[DV + 1] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3], w0[8]};
+#pragma unroll
+            for (int c = 0; c < DV; ++c) out[c] = delay_sample_fast(dv[c], kf, win[c + 1], win[c]);
         } else {
-            for (int c = 0; c < 4 && n0 + c < T; ++c)
-                yb[n0 + c] = warmup ? xb[n0 + c] : delay_sample(xb, bb, D, n0 + c, db[n0 + c]);
+#pragma unroll
+            for (int c = 0; c < DV; ++c) out[c] = delay_sample(xb, bb, D, n0 + c, dv[c]);
+        }
+        *(f32x4 *)(yb + n0) = (f32x4){out[0], out[1], out[2], out[3]};
+        *(f32x4 *)(yb + n0 + 4) = (f32x4){out[4], out[5], out[6], out[7]};
+    } else {
+        for (int c = 0; c < DV && n0 + c < T; ++c) {
+            const float dn = db[n0 + c];
+            bad |= !(dn <= Dmax);
+            yb[n0 + c] = warmup ? xb[n0 + c] : delay_sample(xb, bb, D, n0 + c, dn);
         }
     }
+    if (flag && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
-// buffer <- cat(buffer[T:], x[-D:])   (code/model.py:314-315).  T >= D: pure copy of x's tail.
-// T < D: the surviving D-T samples are staged through `scratch` by the first kernel.
-__global__ __launch_bounds__(256) void delay_stage_kernel(const float *buf, float *scratch, int64_t T, int D,
-                                                          const int32_t *flag)
+// buffer <- cat(buffer[T:], x[-D:])   (code/model.py:314-315), in place, one workgroup per stream.
+// T >= D: the tail of x.  T < D: the surviving D-T samples move down by T -- chunk after chunk in ascending order,
+// every chunk read completely (into registers) before the workgroup barrier that precedes its write, so no source
+// sample is overwritten before it has been read -- then the T new samples follow.
+constexpr int DU_THREADS = 1024;
+__global__ __launch_bounds__(DU_THREADS) void delay_update_kernel(const float *x, float *buf, int64_t T, int D,
+                                                                 const int32_t *flag)
 {
     if (flag && *flag) return;
     const int64_t b = blockIdx.x;
-    const int keep = D - (int)T;
-    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < keep; i += gridDim.y * blockDim.x)
-        scratch[b * keep + i] = buf[b * (int64_t)D + T + i];
-}
-
-__global__ __launch_bounds__(256) void delay_update_kernel(const float *x, float *buf, const float *scratch,
-                                                           int64_t T, int D, const int32_t *flag)
-{
-    if (flag && *flag) return;
-    const int64_t b = blockIdx.x;
+    float *bb = buf + b * (int64_t)D;
+    const float *xb = x + b * T;
     const int keep = T >= D ? 0 : D - (int)T;
-    for (int i = blockIdx.y * blockDim.x + threadIdx.x; i < D; i += gridDim.y * blockDim.x)
-        buf[b * (int64_t)D + i] = i < keep ? scratch[b * keep + i] : x[b * T + (T - (D - keep)) + (i - keep)];
+    for (int c0 = 0; c0 < keep; c0 += DU_THREADS) {
+        const int i = c0 + threadIdx.x;
+        const float v = i < keep ? bb[i + T] : 0.0f;
+        __syncthreads();
+        if (i < keep) bb[i] = v;
+    }
+    const int64_t x0 = T - (D - keep);               // first sample of x that enters the buffer
+    for (int i = keep + threadIdx.x; i < D; i += DU_THREADS) bb[i] = xb[x0 + (i - keep)];
 }
 
 hipError_t launch_delay(const float *x, const float *d, float *y, int64_t B, int64_t T, float *dl_state, int D,
-                        int warmup, float *scratch, int32_t *err_flag, hipStream_t stream)
+                        int warmup, int32_t *err_flag, hipStream_t stream)
 {
     if (B == 0 || T == 0) return hipSuccess;
-    const unsigned gx = (unsigned)((T + 1023) / 1024 > 4096 ? 4096 : (T + 1023) / 1024);     // 4 samples per thread
-    if (err_flag) {
-        hipError_t e = hipMemsetAsync(err_flag, 0, sizeof(int32_t), stream);
-        if (e != hipSuccess) return e;
-        const int64_t n = B * T;
-        const unsigned gc = (unsigned)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
-        hipLaunchKernelGGL(delay_check_kernel, dim3(gc), dim3(256), 0, stream, d, n, (float)D, err_flag);
-    }
-    hipLaunchKernelGGL(delay_apply_kernel, dim3((unsigned)B, gx), dim3(256), 0, stream, x, d, y, B, T, dl_state, D,
+    const int64_t tiles = (T + 256 * DV - 1) / (256 * DV);
+    if (B * tiles > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(delay_apply_kernel, dim3((unsigned)(B * tiles)), dim3(256), 0, stream, x, d, y, B, T, dl_state, D,
                        warmup, err_flag);
-    if (D > 0) {
-        const unsigned gd = (unsigned)((D + 255) / 256);
-        if (T < D)
-            hipLaunchKernelGGL(delay_stage_kernel, dim3((unsigned)B, gd), dim3(256), 0, stream, dl_state, scratch, T,
-                               D, err_flag);
-        hipLaunchKernelGGL(delay_update_kernel, dim3((unsigned)B, gd), dim3(256), 0, stream, x, dl_state, scratch, T,
-                           D, err_flag);
-    }
+    if (D > 0)
+        hipLaunchKernelGGL(delay_update_kernel, dim3((unsigned)B), dim3(DU_THREADS), 0, stream, x, dl_state, T, D, err_flag);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------
-// K3: per-stream ESR sums over samples [skip,T): out[2b] += sum (t-y)^2, out[2b+1] += sum t^2.
-// grid (splits, B); fp64 accumulation; one fp64 atomic pair per block.
+// K3: per-stream ESR sums over samples [skip,T): sum (t-y)^2 and sum t^2 in fp64.
+// grid (B, splits): block (b, p) owns every splits-th 256-sample slab of stream b and writes ITS OWN partial row
+// out[(b * splits + p) * 2 + 0..1] -- no atomics, so the result is bit-reproducible from run to run for every B; the
+// caller adds the `splits` rows of a stream in index order (as ntm_stft_sums' callers do).
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void esr_sums_kernel(const float *y, const float *t, int64_t T, int64_t skip,
                                                        double *out)
@@ -138,23 +171,26 @@ __global__ __launch_bounds__(256) void esr_sums_kernel(const float *y, const flo
     if ((threadIdx.x & 63) == 0) { part[0][wv] = se; part[1][wv] = st; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&out[2 * b + 0], (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]));
-        atomicAdd(&out[2 * b + 1], (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]));
+        double *o = out + (b * gridDim.y + blockIdx.y) * 2;
+        o[0] = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
+        o[1] = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
     }
 }
 
-hipError_t launch_esr(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, double *out,
-                      hipStream_t stream)
+int esr_default_splits(int64_t B, int64_t T, int64_t skip)
 {
-    if (B == 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(double) * 2 * (size_t)B, stream);
-    if (e != hipSuccess) return e;
     const int64_t n = T - skip;
-    if (n <= 0) return hipSuccess;
+    if (B <= 0 || n <= 0) return 1;
     int64_t splits = (n + 4095) / 4096;            // >= 16 samples per thread
     const int64_t want = (2048 + B - 1) / B;       // enough blocks to fill 256 CUs
     if (splits > want) splits = want;
-    if (splits < 1) splits = 1;
+    return (int)(splits < 1 ? 1 : splits);
+}
+
+hipError_t launch_esr(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int splits, double *out,
+                      hipStream_t stream)
+{
+    if (B == 0) return hipSuccess;
     hipLaunchKernelGGL(esr_sums_kernel, dim3((unsigned)B, (unsigned)splits), dim3(256), 0, stream, y, t, T, skip, out);
     return hipGetLastError();
 }

@@ -8,9 +8,10 @@
 
 namespace ntm {
 hipError_t launch_delay(const float *x, const float *d, float *y, int64_t B, int64_t T, float *dl_state, int D,
-                        int warmup, float *scratch, int32_t *err_flag, hipStream_t stream);
-hipError_t launch_esr(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, double *out,
+                        int warmup, int32_t *err_flag, hipStream_t stream);
+hipError_t launch_esr(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int splits, double *out,
                       hipStream_t stream);
+int esr_default_splits(int64_t B, int64_t T, int64_t skip);
 hipError_t launch_esr_dcpre(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, float R, double *out,
                             hipStream_t stream);
 hipError_t launch_stft_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int n_fft, int hop,
@@ -41,7 +42,7 @@ int hip_fail(hipError_t e, const char *where)
 
 extern "C" {
 
-int ntm_abi_version(void) { return 1; }
+int ntm_abi_version(void) { return NTM_ABI_VERSION; }
 
 const char *ntm_last_error(void) { return g_err.c_str(); }
 
@@ -49,11 +50,21 @@ int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, 
                        const float *b_o, int H, const float *x, float *y, int64_t B, int64_t T, int64_t x_stride_b,
                        int64_t y_stride_b, float *h_state, int variant, void *stream)
 {
-    if (H != NTM_HIDDEN) return fail(NTM_EINVAL, "ntm_gru_forward: only hidden size 64 is compiled");
+    if (H != 8 && H != 16 && H != 32 && H != NTM_HIDDEN)
+        return fail(NTM_EINVAL, "ntm_gru_forward: hidden sizes 8, 16, 32 and 64 are compiled");
     if (B < 0 || T < 0) return fail(NTM_EINVAL, "ntm_gru_forward: negative B or T");
     if (B == 0 || T == 0) return NTM_OK;
     if (!w_ih || !w_hh || !b_ih || !b_hh || !w_o || !x || !y) return fail(NTM_EINVAL, "ntm_gru_forward: null pointer");
     if (x_stride_b < T || y_stride_b < T) return fail(NTM_EINVAL, "ntm_gru_forward: stride < T");
+    if (H != NTM_HIDDEN) {
+        // small hidden sizes (the reference's constructor / training defaults, code/model.py:22, code/train.py:50):
+        // one kernel, 64/H streams per wavefront; the matrix-pipe variants exist for H = 64 only
+        if (variant != NTM_GRU_AUTO && variant != NTM_GRU_LAT && variant != NTM_GRU_VALU)
+            return fail(NTM_EINVAL, "ntm_gru_forward: the matrix-pipe kernel variants are compiled for hidden size 64 only");
+        ntm::GruArgs as{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, x_stride_b, y_stride_b, nullptr, 0, 0};
+        hipError_t es = ntm::launch_gru_small(as, H, (hipStream_t)stream);
+        return es == hipSuccess ? NTM_OK : hip_fail(es, "ntm_gru_forward");
+    }
     if (variant == NTM_GRU_VALU && (reinterpret_cast<uintptr_t>(w_hh) & 15))
         return fail(NTM_EINVAL, "ntm_gru_forward: NTM_GRU_VALU reads W_hh with 16-byte loads; w_hh must be 16-byte aligned");
     ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, x_stride_b, y_stride_b, nullptr, 0, 0};
@@ -125,41 +136,37 @@ int ntm_debug_transpose4(const float *in, float *out, void *stream)
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_debug_transpose4");
 }
 
-int64_t ntm_delay_scratch_floats(int64_t B, int64_t T, int D)
-{
-    if (B <= 0 || D <= 0 || T >= D) return 0;
-    return B * (int64_t)(D - (T < 0 ? 0 : T));
-}
-
 int ntm_delay_forward(const float *x, const float *d, float *y, int64_t B, int64_t T, float *dl_state, int D,
-                      int warmup, float *scratch, int32_t *err_flag, void *stream)
+                      int warmup, int32_t *err_flag, void *stream)
 {
     if (B < 0 || T < 0 || D < 0) return fail(NTM_EINVAL, "ntm_delay_forward: negative size");
     if (B == 0 || T == 0) return NTM_OK;
     if (!x || !d || !y || (D > 0 && !dl_state)) return fail(NTM_EINVAL, "ntm_delay_forward: null pointer");
     if (x == y) return fail(NTM_EINVAL, "ntm_delay_forward: y must not alias x");
-    if (T < D && !scratch) return fail(NTM_EINVAL, "ntm_delay_forward: scratch required when T < D");
-    hipError_t e = ntm::launch_delay(x, d, y, B, T, dl_state, D, warmup, scratch, err_flag, (hipStream_t)stream);
+    hipError_t e = ntm::launch_delay(x, d, y, B, T, dl_state, D, warmup, err_flag, (hipStream_t)stream);
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_delay_forward");
 }
 
 int ntm_diffdel_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
                             const float *w_o, int H, const float *x, const float *d, float *y, float *pre_d,
-                            int64_t B, int64_t T, float *h_state, float *dl_state, int D, int warmup, float *scratch,
+                            int64_t B, int64_t T, float *h_state, float *dl_state, int D, int warmup,
                             int32_t *err_flag, void *stream)
 {
     if (!pre_d || pre_d == y) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: pre_d must be a distinct buffer");
     int rc = ntm_gru_forward(w_ih, w_hh, b_ih, b_hh, w_o, nullptr, H, x, pre_d, B, T, T, T, h_state, stream);
     if (rc != NTM_OK) return rc;
-    return ntm_delay_forward(pre_d, d, y, B, T, dl_state, D, warmup, scratch, err_flag, stream);
+    return ntm_delay_forward(pre_d, d, y, B, T, dl_state, D, warmup, err_flag, stream);
 }
 
-int ntm_esr_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, double *out, void *stream)
+int ntm_esr_splits(int64_t B, int64_t T, int64_t skip) { return ntm::esr_default_splits(B, T, skip); }
+
+int ntm_esr_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int splits, double *out, void *stream)
 {
     if (B < 0 || T < 0 || skip < 0 || skip > T) return fail(NTM_EINVAL, "ntm_esr_sums: bad size");
+    if (splits < 1 || splits > 65535) return fail(NTM_EINVAL, "ntm_esr_sums: splits must be in [1, 65535]");
     if (B == 0) return NTM_OK;
     if (!y || !t || !out) return fail(NTM_EINVAL, "ntm_esr_sums: null pointer");
-    hipError_t e = ntm::launch_esr(y, t, B, T, skip, out, (hipStream_t)stream);
+    hipError_t e = ntm::launch_esr(y, t, B, T, skip, splits, out, (hipStream_t)stream);
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_esr_sums");
 }
 

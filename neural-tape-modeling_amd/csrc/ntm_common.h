@@ -7,7 +7,7 @@ namespace ntm {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kH = 64;  // hidden size (NTM_HIDDEN)
+constexpr int kH = 64;  // hidden size of the matrix-pipe / low-latency kernels (NTM_HIDDEN); gru_small.hip: 8, 16, 32
 
 // sigma(v) = 1/(1+e^-v) on v_exp_f32 / v_rcp_f32 (both ~1 ulp).  Saturates cleanly:
 // e^-v -> inf gives 0, -> 0 gives 1.
@@ -54,5 +54,6 @@ hipError_t launch_gru_valu(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_mfma3(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_lat(const GruArgs &a, hipStream_t stream);
+hipError_t launch_gru_small(const GruArgs &a, int H, hipStream_t stream);   // H = 8, 16, 32
 hipError_t launch_debug_transpose(const float *in, float *out, hipStream_t stream);
 }  // namespace ntm

@@ -346,6 +346,7 @@ class SegmentFeeder:
             if B != 1:
                 model.hidden = model.hidden.expand(1, B, model.hidden_size).contiguous()
                 model.diffdel.buffer = model.diffdel.buffer.expand(B, 1, -1).contiguous()
+            deferred, model.diffdel.defer_check = model.diffdel.defer_check, True   # no host sync per chunk
         else:
             model.initialize_hidden()
             model.warm_start()
@@ -373,6 +374,10 @@ class SegmentFeeder:
             ev = nxt
         if back is not None:
             cur.wait_stream(back)                               # a sync of the caller's stream covers the copies back
+        if is_dd:
+            model.diffdel.defer_check = deferred
+            if not deferred:
+                model.diffdel.raise_if_violated()              # the assert of code/model.py:284, once for all chunks
         for a in (x, t, dtr):
             if a is not None:
                 a.record_stream(side)

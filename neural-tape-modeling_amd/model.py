@@ -74,8 +74,10 @@ class _GRUHead(torch.nn.Module):
         if input_size != 1 or output_size != 1:
             raise ValueError("only input_size = output_size = 1 is built (every reference checkpoint and "
                              "caller uses 1: code/test-model.py:123-124)")
-        if hidden_size != 64:
-            raise ValueError("only hidden_size = 64 is compiled (all shipped checkpoints are HS[64])")
+        if hidden_size not in _lib.HIDDEN_SIZES:
+            raise ValueError(f"hidden_size {hidden_size}: the kernels are compiled for {_lib.HIDDEN_SIZES} "
+                             "(reference default 8, code/model.py:22; training default 16, code/train.py:50; "
+                             "every shipped checkpoint is HS[64])")
         self.input_size, self.hidden_size, self.output_size, self.skip = input_size, hidden_size, output_size, skip
         self.GRU = _GRUParams(input_size, hidden_size)
         self.output = _LinearParams(hidden_size, output_size, bias=head_bias)
@@ -174,7 +176,16 @@ class RNN(_GRUHead):
 
 
 class TimeVaryingDelayLine(torch.nn.Module):
-    """Time-varying feed-forward delay line, linear interpolation (reference: code/model.py:249-332)."""
+    """Time-varying feed-forward delay line, linear interpolation (reference: code/model.py:249-332).
+
+    The reference asserts `max_delay >= max(dt)` at the top of forward() (code/model.py:284).  Here the range check
+    rides along in the kernel that reads dt anyway and raises a device-side flag; the carried buffer is never
+    modified by a violating call (nor by any later one until the flag is cleared), exactly the state the reference
+    is left in when its assert fires.  forward() by default looks at the flag before it returns, so a direct call
+    raises AssertionError where the reference does (one host synchronisation, as `torch.max(dt)` in the reference's
+    assert is).  Callers that stream many chunks set `defer_check = True` (DiffDelRNN.predict, the feeder's
+    streamed predict, BlockStreamer-style loops do): no host synchronisation per call, `raise_if_violated()` once at
+    the end."""
 
     def __init__(self, max_delay=40000, channels=1):
         super().__init__()
@@ -184,32 +195,39 @@ class TimeVaryingDelayLine(torch.nn.Module):
         # like the reference, batch 2 until init_buffer() is called (code/model.py:267)
         self.buffer = torch.zeros(2, channels, max_delay)
         self._err = None
+        self.defer_check = False
 
     def init_buffer(self, N, max_d):
         """Zero buffer for mini-batch size N; overwrites max_delay (code/model.py:326-332)."""
         device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
         self.max_delay = max_d
         self.buffer = torch.zeros(N, 1, self.max_delay).to(device)
+        if self._err is not None:
+            self._err.zero_()
+
+    def raise_if_violated(self):
+        """The reference's `assert self.max_delay >= torch.max(dt)` for every forward() since the last check
+        (one host synchronisation).  The buffer holds the state before the first violating call."""
+        if self._err is not None and int(self._err.item()) != 0:
+            self._err.zero_()
+            raise AssertionError("max_delay >= max(dt) violated")
 
     def _run(self, xbt, dbt, warmup):
+        """[B,T] fp32 -> y [B,T]; the carried buffer is updated IN PLACE (no clone, no scratch, no host sync)."""
         B, T = xbt.shape
         D = int(self.max_delay)
         if self.buffer.shape[0] != B or self.buffer.shape[2] != D:
             raise RuntimeError(f"Sizes of tensors must match: buffer {list(self.buffer.shape)} vs input batch {B}")
-        buf = self.buffer.to(device=xbt.device, dtype=torch.float32).contiguous().clone()
-        y = torch.empty_like(xbt)
-        L = _lib.lib()
-        ns = L.ntm_delay_scratch_floats(B, T, D)
-        scratch = torch.empty(max(ns, 1), device=xbt.device, dtype=torch.float32)
+        if self.buffer.device != xbt.device or self.buffer.dtype != torch.float32 or not self.buffer.is_contiguous():
+            self.buffer = self.buffer.to(device=xbt.device, dtype=torch.float32).contiguous()
         if self._err is None or self._err.device != xbt.device:
             self._err = torch.zeros(1, device=xbt.device, dtype=torch.int32)
-        rc = L.ntm_delay_forward(ptr(xbt), ptr(dbt), ptr(y), B, T, ptr(buf), D, int(bool(warmup)), ptr(scratch),
-                                 ptr(self._err), _lib.current_stream())
+        y = torch.empty_like(xbt)
+        rc = _lib.lib().ntm_delay_forward(ptr(xbt), ptr(dbt), ptr(y), B, T, ptr(self.buffer), D, int(bool(warmup)),
+                                          ptr(self._err), _lib.current_stream())
         _lib.check(rc, "ntm_delay_forward")
-        # the reference asserts before touching anything (code/model.py:284); the kernels skip all
-        # writes when the flag is set, so state is equally untouched.
-        assert int(self._err.item()) == 0, "max_delay >= max(dt) violated"
-        self.buffer = buf
+        if not self.defer_check:
+            self.raise_if_violated()
         return y
 
     @torch.no_grad()
@@ -247,35 +265,51 @@ class DiffDelRNN(_GRUHead):
             _, __ = self(x, d_traj)
 
     @torch.no_grad()
-    def forward(self, x, del_traj, warmup=False):
-        """(x, del_traj) (N,1,T) -> (y, pre_d) (code/model.py:393-424)."""
+    def forward(self, x, del_traj, warmup=False, _events=None):
+        """(x, del_traj) (N,1,T) -> (y, pre_d) (code/model.py:393-424).  `_events`: three torch.cuda.Event objects
+        recorded before the GRU launch, between it and the delay pass, and after (bench.py's per-kernel timing)."""
         xbt = _as_bt(x, "DiffDelRNN.forward")
         dbt = _as_bt(del_traj, "DiffDelRNN.forward")
         if dbt.shape != xbt.shape:
             raise RuntimeError(f"shape mismatch: x {tuple(x.shape)} vs del_traj {tuple(del_traj.shape)}")
+        if _events:
+            _events[0].record()
         pre = self._gru(xbt)
         if self.skip:
             pre += xbt
+        if _events:
+            _events[1].record()
         y = self.diffdel._run(pre, dbt, warmup)
+        if _events:
+            _events[2].record()
         B, T = xbt.shape
         return y.view(B, 1, T), pre.view(B, 1, T)
 
     @torch.no_grad()
-    def predict(self, input, d_traj, segment_length=None):
-        """initialize_hidden + warm_start + forward (code/model.py:618-653); any batch size."""
+    def predict(self, input, d_traj, segment_length=None, _events=None):
+        """initialize_hidden + warm_start + forward (code/model.py:618-653); any batch size.  The delay-range assert
+        of code/model.py:284 is evaluated ONCE, after the last chunk has been enqueued (no host synchronisation
+        per chunk)."""
         B, T = input.shape[0], input.shape[-1]
         self.initialize_hidden(1, self.max_delay)
         self.warm_start()
         if B != 1:
             self.hidden = self.hidden.expand(1, B, self.hidden_size).contiguous()
             self.diffdel.buffer = self.diffdel.buffer.expand(B, 1, -1).contiguous()
-        if segment_length is None:
-            return self.forward(input, d_traj)
-        output = torch.empty(input.shape, device=input.device, dtype=torch.float32)
-        output_pre_d = torch.empty(input.shape, device=input.device, dtype=torch.float32)
-        for i in range(int(np.ceil(T / segment_length))):
-            sl = slice(i * segment_length, (i + 1) * segment_length)
-            output[:, :, sl], output_pre_d[:, :, sl] = self.forward(input[:, :, sl], d_traj[:, :, sl])
+        deferred, self.diffdel.defer_check = self.diffdel.defer_check, True
+        try:
+            if segment_length is None:
+                output, output_pre_d = self.forward(input, d_traj, _events=_events)
+            else:
+                output = torch.empty(input.shape, device=input.device, dtype=torch.float32)
+                output_pre_d = torch.empty(input.shape, device=input.device, dtype=torch.float32)
+                for i in range(int(np.ceil(T / segment_length))):
+                    sl = slice(i * segment_length, (i + 1) * segment_length)
+                    output[:, :, sl], output_pre_d[:, :, sl] = self.forward(input[:, :, sl], d_traj[:, :, sl])
+        finally:
+            self.diffdel.defer_check = deferred
+        if not deferred:
+            self.diffdel.raise_if_violated()
         return output, output_pre_d
 
 
@@ -291,10 +325,13 @@ def esr_sums(output, target, skip=0):
     y = _as_bt(output, "esr_sums")
     t = _as_bt(target, "esr_sums")
     B, T = y.shape
-    out = torch.empty(B, 2, device=y.device, dtype=torch.float64)
-    rc = _lib.lib().ntm_esr_sums(ptr(y), ptr(t), B, T, int(skip), ptr(out), _lib.current_stream())
+    L = _lib.lib()
+    splits = L.ntm_esr_splits(B, T, int(skip))
+    out = torch.empty(B, splits, 2, device=y.device, dtype=torch.float64)
+    rc = L.ntm_esr_sums(ptr(y), ptr(t), B, T, int(skip), splits, ptr(out), _lib.current_stream())
     _lib.check(rc, "ntm_esr_sums")
-    return out
+    # the partial rows of a stream are added in index order (deterministic: no atomics on either side)
+    return out[:, 0] if splits == 1 else out.sum(dim=1)
 
 
 def esr_per_segment(output, target, skip=0):

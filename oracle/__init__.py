@@ -36,9 +36,11 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libntm_oracle.so")
+        path = os.environ.get("NTM_ORACLE_LIB") or os.path.join(_HERE, "libntm_oracle.so")   # override: the asan build
         if not os.path.exists(path):
-            build()
+            # never built lazily: a caller such as bench.py's cpu_baseline leg runs after the GPU is initialised and
+            # must not spawn a compiler there -- __graft_entry__.build() / `make -C oracle` build it up front
+            raise RuntimeError(f"{path} is missing: build the oracle first (`make -C {_HERE}` or __graft_entry__.build())")
         _LIB = ctypes.CDLL(path)
         _LIB.ntmo_gru_forward.argtypes = [_f32p] * 6 + [ctypes.c_int, _f32p, _f32p,
                                                         ctypes.c_int64, ctypes.c_int64, _f32p]
@@ -52,6 +54,7 @@ def lib():
         _LIB.ntmo_tape_hmag.argtypes = [_f64p, _f64p, ctypes.c_int64, ctypes.c_int64, _f64p, ctypes.c_double, _f64p]
         _LIB.ntmo_tcn_forward.argtypes = [_f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, _i32p,
                                           _f32p, _f32p, ctypes.c_int64, ctypes.c_int64]
+        _LIB.ntmo_tcn_forward_mt.argtypes = _LIB.ntmo_tcn_forward.argtypes + [ctypes.c_int]
     return _LIB
 
 
@@ -124,14 +127,14 @@ def delay_forward(x, d, buf, warmup=False):
     return y, buf
 
 
-def diffdel_forward(w, x, d, h, buf, warmup=False):
+def diffdel_forward(w, x, d, h, buf, warmup=False, threads=1):
     """DiffDelRNN.forward, code/model.py:393-424 -> (y, pre_d, h_out, buf_out)."""
-    pre, h = gru_forward(w, x, h)
+    pre, h = gru_forward(w, x, h, threads)
     y, buf = delay_forward(pre, d, buf, warmup)
     return y, pre, h, buf
 
 
-def diffdel_predict(w, x, d, max_delay):
+def diffdel_predict(w, x, d, max_delay, threads=1):
     """DiffDelRNN.predict, code/model.py:618-653, batched generalisation (same warm state for all
     streams: zero input, zero delay for 1024 samples)."""
     x, d = _c(x), _c(d)
@@ -139,7 +142,7 @@ def diffdel_predict(w, x, d, max_delay):
     D = int(max_delay) + 1                                  # code/model.py:372-375
     z = np.zeros((1, 1024), np.float32)
     _, _, h1, b1 = diffdel_forward(w, z, z, None, np.zeros((1, D), np.float32))
-    return diffdel_forward(w, x, d, np.repeat(h1, B, 0), np.repeat(b1, B, 0))
+    return diffdel_forward(w, x, d, np.repeat(h1, B, 0), np.repeat(b1, B, 0), threads=threads)
 
 
 def esr_sums(y, t, skip=0):
@@ -305,13 +308,14 @@ def tape_hmag(H, state=None, Ts=1.0 / (48000 * 16), params=TAPE_PARAMS):
     return M, state
 
 
-def tcn_forward(params, L, C, K, dil, x):
+def tcn_forward(params, L, C, K, dil, x, threads=1):
     x = _c(x)
     B, T = x.shape
     y = np.empty_like(x)
     params = _c(params)
     dil = np.ascontiguousarray(dil, dtype=np.int32)
-    assert lib().ntmo_tcn_forward(_p(params), L, C, K, dil.ctypes.data_as(_i32p), _p(x), _p(y), B, T) == 0
+    args = [_p(params), L, C, K, dil.ctypes.data_as(_i32p), _p(x), _p(y), B, T]
+    assert (lib().ntmo_tcn_forward_mt(*args, threads) if threads > 1 else lib().ntmo_tcn_forward(*args)) == 0
     return y
 
 

@@ -257,46 +257,59 @@ int ntmo_tape_hmag(const double *H, double *M, int64_t B, int64_t N, double *sta
  * Parameters are packed block after block: W[C_in][K][C_out], b[C_out], a[C_out], res_w[C_in][C_out]
  * (always present), then out_w[C], out_b[1]  (output channel fastest: the layout the kernel streams).
  */
+static void tcn_stream(const float *params, int L, int C, int K, const int *dil, const float *x, float *y, int64_t T)
+{
+    float *a = (float *)malloc(sizeof(float) * (size_t)C * (size_t)T);
+    float *c = (float *)malloc(sizeof(float) * (size_t)C * (size_t)T);
+    int cin = 1;
+    const float *p = params;
+    memcpy(a, x, sizeof(float) * (size_t)T);
+    for (int l = 0; l < L; ++l) {
+        const float *W = p;            p += (size_t)C * cin * K;
+        const float *bias = p;         p += C;
+        const float *alpha = p;        p += C;
+        const float *rw = p;           p += (size_t)C * cin;
+        for (int co = 0; co < C; ++co) {
+            for (int64_t n = 0; n < T; ++n) {
+                float u = bias[co];
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int k = 0; k < K; ++k) {
+                        const int64_t src = n - (int64_t)(K - 1 - k) * dil[l];
+                        if (src >= 0) u += W[((size_t)ci * K + k) * C + co] * a[(size_t)ci * T + src];
+                    }
+                const float v = u >= 0.0f ? u : alpha[co] * u;
+                float r = 0.0f;
+                for (int ci = 0; ci < cin; ++ci) r += rw[(size_t)ci * C + co] * a[(size_t)ci * T + n];
+                c[(size_t)co * T + n] = v + r;
+            }
+        }
+        float *tmp = a; a = c; c = tmp;
+        cin = C;
+    }
+    const float *ow = p, *ob = p + C;
+    for (int64_t n = 0; n < T; ++n) {
+        float acc = ob[0];
+        for (int ci = 0; ci < C; ++ci) acc += ow[ci] * a[(size_t)ci * T + n];
+        y[n] = acc;
+    }
+    free(a);
+    free(c);
+}
+
 int ntmo_tcn_forward(const float *params, int L, int C, int K, const int *dil, const float *x,
                      float *y, int64_t B, int64_t T)
 {
     if (L <= 0 || C <= 0 || K <= 0) return -1;
-    float *a = (float *)malloc(sizeof(float) * (size_t)C * (size_t)T);
-    float *c = (float *)malloc(sizeof(float) * (size_t)C * (size_t)T);
-    for (int64_t b = 0; b < B; ++b) {
-        int cin = 1;
-        const float *p = params;
-        memcpy(a, x + b * T, sizeof(float) * (size_t)T);
-        for (int l = 0; l < L; ++l) {
-            const float *W = p;            p += (size_t)C * cin * K;
-            const float *bias = p;         p += C;
-            const float *alpha = p;        p += C;
-            const float *rw = p;           p += (size_t)C * cin;
-            for (int co = 0; co < C; ++co) {
-                for (int64_t n = 0; n < T; ++n) {
-                    float u = bias[co];
-                    for (int ci = 0; ci < cin; ++ci)
-                        for (int k = 0; k < K; ++k) {
-                            const int64_t src = n - (int64_t)(K - 1 - k) * dil[l];
-                            if (src >= 0) u += W[((size_t)ci * K + k) * C + co] * a[(size_t)ci * T + src];
-                        }
-                    const float v = u >= 0.0f ? u : alpha[co] * u;
-                    float r = 0.0f;
-                    for (int ci = 0; ci < cin; ++ci) r += rw[(size_t)ci * C + co] * a[(size_t)ci * T + n];
-                    c[(size_t)co * T + n] = v + r;
-                }
-            }
-            float *tmp = a; a = c; c = tmp;
-            cin = C;
-        }
-        const float *ow = p, *ob = p + C;
-        for (int64_t n = 0; n < T; ++n) {
-            float acc = ob[0];
-            for (int ci = 0; ci < C; ++ci) acc += ow[ci] * a[(size_t)ci * T + n];
-            y[b * T + n] = acc;
-        }
-    }
-    free(a);
-    free(c);
+    for (int64_t b = 0; b < B; ++b) tcn_stream(params, L, C, K, dil, x + b * T, y + b * T, T);
+    return 0;
+}
+
+/* streams over OpenMP threads (the full-size parity tests check several 65 536-sample streams) */
+int ntmo_tcn_forward_mt(const float *params, int L, int C, int K, const int *dil, const float *x,
+                        float *y, int64_t B, int64_t T, int threads)
+{
+    if (L <= 0 || C <= 0 || K <= 0) return -1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads)
+    for (int64_t b = 0; b < B; ++b) tcn_stream(params, L, C, K, dil, x + b * T, y + b * T, T);
     return 0;
 }

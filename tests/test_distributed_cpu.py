@@ -79,3 +79,44 @@ def test_local_sums_and_reduce_many_single_process():
     b = D.reduce_many([D.local_loss_sums(per, sums), D.local_loss_sums(2 * per, None)])
     assert a == b[0] and abs(a["mean_segment_loss"] - 0.7 / 3) < 1e-15 and a["sum_err2"] == 9.0 and a["sum_tgt2"] == 12.0
     assert abs(b[1]["mean_segment_loss"] - 1.4 / 3) < 1e-15 and b[1]["sum_err2"] == 0.0 and D.reduce_many([]) == []
+
+
+def _run_bench(args, env_extra=None):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=300)
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, lines
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment (how the driver runs it): the parent spawns N
+    rank processes, relays rank 0's single JSON line, returns 0 -- here with the data path switched off
+    (--launch-check, CPU, gloo); the GPU variant of this test runs the real step on the GPU box."""
+    r, lines = _run_bench(["--gpus", "2", "--launch-check"])
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert lines == [{"launch_check": True, "world": 2, "segments_total": 8192, "rank_sum": 1, "ranks": 2, "scaling": "weak"}]
+    # strong scaling: 10 segments over 3 ranks = 4 + 3 + 3
+    r, lines = _run_bench(["--gpus", "3", "--launch-check", "--scaling", "strong", "--total-batch", "10"])
+    assert r.returncode == 0 and lines[0]["segments_total"] == 10 and lines[0]["ranks"] == 3
+
+
+def test_bench_launcher_propagates_a_failing_rank():
+    r, lines = _run_bench(["--gpus", "2", "--launch-check", "--fail-rank", "1"])
+    assert r.returncode != 0 and "rank 1 exited with status 3" in r.stderr
+
+
+def test_bench_under_an_external_launcher_keeps_working():
+    """RANK / WORLD_SIZE given by a launcher (torch.distributed.run style): bench.py must NOT spawn again."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert '"world": 2' in outs[0][0] and "{" not in outs[1][0]        # only rank 0 prints the JSON line

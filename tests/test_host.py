@@ -26,18 +26,24 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libntm.so does not export {s}"
     assert set(ntm_amd._lib._SIGNATURES) == set(syms)       # the ctypes table covers the whole header
-    assert ntm_amd._lib.lib().ntm_abi_version() == 1
+    assert ntm_amd._lib.lib().ntm_abi_version() == 2 == ntm_amd._lib.ABI_VERSION
 
 
 def test_cabi_pure_host_entry_points():
     L = ntm_amd._lib.lib()
-    assert L.ntm_delay_scratch_floats(4, 100, 37) == 0
-    assert L.ntm_delay_scratch_floats(4, 20, 37) == 4 * 17
     assert L.ntm_tcn_scratch_floats(2, 100, 32) == 2 * 2 * 100 * 32
     # argument validation happens before anything touches a device
+    assert L.ntm_gru_forward(None, None, None, None, None, None, 24, None, None, 1, 1, 1, 1, None, None) == -1
+    assert b"8, 16, 32 and 64" in L.ntm_last_error()
     assert L.ntm_gru_forward(None, None, None, None, None, None, 8, None, None, 1, 1, 1, 1, None, None) == -1
-    assert b"64" in L.ntm_last_error()
-    assert L.ntm_esr_sums(None, None, 1, 10, 11, None, None) == -1
+    assert b"null pointer" in L.ntm_last_error()
+    # the matrix-pipe variants exist for H = 64 only (checked before any device call)
+    one = ctypes.c_void_p(16)
+    assert L.ntm_gru_forward_ex(one, one, one, one, one, None, 16, one, one, 1, 1, 1, 1, None,
+                                ntm_amd._lib.NTM_GRU_MFMA2, None) == -1
+    assert b"hidden size 64 only" in L.ntm_last_error()
+    assert L.ntm_esr_sums(None, None, 1, 10, 11, 1, None, None) == -1
+    assert L.ntm_esr_splits(4096, 65536, 1024) == 1 and L.ntm_esr_splits(1, 65536, 0) == 16 and L.ntm_esr_splits(16, 8192, 0) == 2
 
 
 def test_name_parsers_match_reference_table():
@@ -70,8 +76,16 @@ def test_state_dict_protocol():
             assert np.array_equal(v.numpy(), ref[k])
     with pytest.raises(RuntimeError):                          # strict load like torch: bias key missing
         m.load_state_dict(ntm_amd.weights.load_state_dict(ntm_amd.weights.W_DIFFDEL))
+    # the reference's own defaults construct (code/model.py:22: hidden_size=8; code/train.py:50: 16)
+    for H in (8, 16, 32):
+        r = ntm_amd.RNN() if H == 8 else ntm_amd.RNN(1, H, 1)
+        assert r.hidden_size == H and tuple(r.GRU.weight_hh_l0.shape) == (3 * H, H)
+        assert sum(p.numel() for p in r.parameters()) == 3 * H * H + 3 * H + 6 * H + H + 1
+        torch_ref = torch.nn.GRU(1, H, batch_first=True)
+        assert {k: tuple(v.shape) for k, v in r.GRU.state_dict().items()} == \
+               {k: tuple(v.shape) for k, v in torch_ref.state_dict().items()}
     with pytest.raises(ValueError):
-        ntm_amd.RNN(1, 8, 1)                                   # reference default H=8 is not compiled
+        ntm_amd.RNN(1, 24, 1)                                  # not one of the compiled sizes
 
 
 def test_no_cpu_fallback():

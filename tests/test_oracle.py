@@ -186,3 +186,35 @@ def test_g13_power_spectrogram_metrics_against_torch_stft():
     g10, g = load("g10_mrstft.npz"), load("g13_ms_spec.npz")
     lin, log = oracle.ms_spec_losses(g10["pred"], g10["targ"])
     assert abs(lin / float(g["ms_spec_loss"]) - 1) < 1e-6 and abs(log / float(g["ms_log_spec_loss"]) - 1) < 1e-6
+
+
+def _g16_weights(g, prefix):
+    import oracle
+    sd = {k[len(prefix):]: g[k] for k in g.files if k.startswith(prefix)}
+    return oracle.Weights.from_state_dict(sd)
+
+
+@pytest.mark.parametrize("H", [8, 16, 32])
+def test_g16_hidden_sizes_reference_defaults(H):
+    """The reference's RNN with its default hidden sizes (code/model.py:22: 8; code/train.py:50: 16) and 32, random
+    weights from its own constructor: predict per stream and batched forward with state carry."""
+    g = load("g16_hidden_sizes.npz")
+    w = _g16_weights(g, f"sd_{H}_")
+    assert w.H == H and w.b_o is not None
+    x = g[f"x_{H}"][:, 0, :]
+    y, _ = oracle.gru_predict(w, x)
+    assert np.abs(y - g[f"y_{H}_predict"][:, 0, :]).max() < GRU_TOL
+    y0, h = oracle.gru_forward(w, x[:, :700])
+    y1, h = oracle.gru_forward(w, x[:, 700:], h)
+    assert np.abs(np.concatenate([y0, y1], 1) - g[f"y_{H}_carry"][:, 0, :]).max() < GRU_TOL
+    assert np.abs(h - g[f"h_{H}_carry"][0]).max() < GRU_TOL
+
+
+def test_g16_diffdel_hidden_16():
+    g = load("g16_hidden_sizes.npz")
+    w = _g16_weights(g, "dd_sd_")
+    assert w.H == 16 and w.b_o is None
+    y, pre, h, buf = oracle.diffdel_predict(w, g["dd_x"][:, 0, :], g["dd_d"][:, 0, :], int(g["dd_max_delay"]))
+    assert np.abs(pre - g["dd_pre_d"][:, 0, :]).max() < GRU_TOL
+    assert np.abs(y - g["dd_y"][:, 0, :]).max() < GRU_TOL
+    assert np.abs(buf - g["dd_buffer"][:, 0, :]).max() < GRU_TOL and np.abs(h - g["dd_hidden"][0]).max() < GRU_TOL

@@ -37,6 +37,9 @@ def main(argv=None):
     p.add_argument('--DEMODULATE', action='store_true', default=False)
     p.add_argument('--ADD_DELAY', action='store_true', default=False,
                    help="GRU only: apply the measured delay trajectory to the model output (code/test-model.py:236-240,355-364)")
+    p.add_argument('--INIT_LEN', type=int, default=None,
+                   help="samples cut from the head of every segment before the losses; default: the reference's "
+                        "nextpow2(int(max_delay * fs)) (code/test-model.py:323-324), i.e. 2 for a dataset without delay")
     p.add_argument('--KERNEL', type=str, default="auto")
     a = p.parse_args(argv)
 
@@ -52,12 +55,15 @@ def main(argv=None):
     model = ntm_amd.harness.build_model(name, max_delay_seconds=a.MAX_DELAY, fs=feeder.fs, state_dict=sd)
     model.kernel_variant = a.KERNEL
     is_dd = isinstance(model, ntm_amd.DiffDelRNN)
-    init_len = ntm_amd.harness.init_len(a.MAX_DELAY, feeder.fs) if a.MAX_DELAY > 0 else 2**10
+    # code/test-model.py:323-324: INIT_LEN = nextpow2(int(max_delay * fs)) -- for max_delay == 0 that is 2 (the
+    # reference's own "# 2**10" comment there is wrong: nextpow2(0) == 2)
+    init_len = a.INIT_LEN if a.INIT_LEN is not None else ntm_amd.harness.init_len(a.MAX_DELAY, feeder.fs)
     if not a.COMPUTE_LOSS:
         print(f"{len(feeder)} segments of {feeder.length} samples @ {feeder.fs} Hz; nothing to do without --COMPUTE_LOSS")
         return {}
     per = {"ESR": [], "DCPreESR": [], "MultiSTFT": []}
     mrstft = ntm_amd.MRSTFTLoss()
+    with_stft = feeder.length - init_len > 1024               # the largest STFT frame needs > 1024 samples
     def batches():
         if a.DEMODULATE or a.ADD_DELAY or a.STREAM_CHUNK <= 0:
             for xin, tgt, dt, _ in feeder.batches(a.BATCH_SIZE, "cuda", rank, world):
@@ -85,9 +91,11 @@ def main(argv=None):
         for key, fn in (("ESR", esr_sums), ("DCPreESR", esr_dcpre_sums)):
             s = fn(out, tgt, skip=init_len)
             per[key].append((s[:, 0] / n) / (s[:, 1] / n + ESR_EPS))
-        if n > 1024:                                          # the largest STFT frame needs > 1024 samples
+        if with_stft:
             per["MultiSTFT"].append(mrstft.per_segment(out, tgt, skip=init_len))
-    if not per["MultiSTFT"]:
+    # every rank issues the SAME collectives whatever its shard holds (a rank with no segments -- more ranks than
+    # segments -- reduces empty tensors): the key set depends on the global segment length only
+    if not with_stft:
         del per["MultiSTFT"]
     res = {k: D.reduce_loss_sums(torch.cat(v) if v else torch.zeros(0, device="cuda", dtype=torch.float64))
            for k, v in per.items()}
