@@ -51,58 +51,95 @@ __device__ __forceinline__ float delay_sample_fast(float dn, float kf, float xa,
     return acc;
 }
 
-// thread -> DV consecutive samples (DV = 8: two 16-byte loads of d, two 16-byte stores of y).  Fast path, taken when
-// the DV delays of the thread share one integer part k with 0 <= k < D and the window lies inside x: the DV + 1
-// samples x[n0-k-1 .. n0+DV-1-k] the taps need are contiguous -> two 16-byte loads at 4-byte alignment + one dword
-// instead of 2 DV scalar gathers.  Everything else (k changes inside the thread's run, history taps, k = D, d < 0,
-// NaN) goes through delay_sample().  HBM-bound pass: 12 B/sample (d, x once, y).
-constexpr int DV = 8;
+// A 256-thread workgroup covers DG runs of 1024 consecutive samples of one stream; in a run thread i owns the 4
+// samples 4i..4i+3, so every 16-byte access of a wavefront (d load, tap window, y store) is lane-contiguous -- 1 KB per
+// instruction, fully coalesced; the d loads of all runs are issued before anything else.
+// Fast path, taken when the 4 delays of a thread share one integer part k with 0 <= k < D and the window lies inside
+// x: the 5 samples x[n0-k-1 .. n0+3-k] the taps need are contiguous -> one 16-byte load at 4-byte alignment + one
+// dword instead of 8 scalar gathers.  Everything else (k changes inside the run, history taps, k = D, d < 0, NaN) goes
+// through delay_sample().  HBM-bound pass: 12 B/sample (d, x once, y).  Sample indices inside a stream are 32-bit
+// (T < 2^31) and the classification avoids float -> int64 conversions: at 4 samples per thread the pass is as much
+// instruction-bound as memory-bound.
+// History of the shape at 4096 x 65 536, D = 1847 (tools/delay_probe.py; torch's two-in one-out elementwise add, the
+// same traffic, takes 0.54 ms): four launches with a separate range-check pass ~1.5 ms | one pass, 8 consecutive
+// samples per thread (32-byte lane stride) 1.03 | 4 per thread, two runs per workgroup 0.89 | XCD-aware ids 0.85 |
+// a loop of 8 runs per workgroup with the next d prefetched 0.99 (worse: dropped) | 32-bit lean classification with
+// unconditional window loads (all four loads of a workgroup's two runs in flight together) 0.81 = 4.1 TB/s.
+constexpr int DV = 4;            // samples per thread and run
+constexpr int DRUN = 256 * DV;   // samples per run
+constexpr int DG = 2;            // runs per workgroup
+template <bool NT>               // nontemporal d / y accesses
 __global__ __launch_bounds__(256) void delay_apply_kernel(const float *x, const float *d, float *y, int64_t B,
-                                                          int64_t T, const float *buf, int D, int warmup,
-                                                          int32_t *flag)
+                                                          int T, const float *buf, int D, int warmup,
+                                                          int32_t *flag, unsigned tiles_u)
 {
-    if (flag && *flag) return;                       // sticky: an earlier violation froze this state
-    const int64_t tiles = (T + 256 * DV - 1) / (256 * DV);
-    const int64_t b = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+    // XCD-aware mapping (speed only): workgroups are dealt round-robin over the 8 XCDs, so ids l and l + 8 share an
+    // L2.  All tiles of a stream get the same l % 8 and follow each other on that XCD: the tap window of a tile (it
+    // reaches up to D samples back into the previous tile's part of x) is then in THAT L2 instead of being fetched a
+    // second time through the fabric by another XCD.
+    const unsigned l = blockIdx.x, j = l >> 3;
+    const unsigned tile = j % tiles_u;
+    const int64_t b = (int64_t)(j / tiles_u) * 8 + (l & 7);
+    if (b >= B) return;
     const float *xb = x + b * T, *db = d + b * T, *bb = buf + b * (int64_t)D;
     float *yb = y + b * T;
     const float Dmax = (float)D;
     const bool vec = ((T & 3) == 0) && (((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(y)) & 15) == 0);
-    const int64_t n0 = (tile * 256 + threadIdx.x) * DV;
+    const int base = (int)(tile * (unsigned)(DRUN * DG)) + (int)threadIdx.x * DV;
     int bad = 0;
-    if (n0 + DV <= T && vec) {
-        const f32x4 d0 = *(const f32x4 *)(db + n0), d1 = *(const f32x4 *)(db + n0 + 4);
-        float dv[DV] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
-        const float kf = floorf(dv[0]);
-        bool same = kf >= 0.0f && kf < Dmax && (n0 - (int64_t)kf - 1) >= 0;
+    if (vec && base + (DG - 1) * DRUN + DV <= T) {
+        // ---- hot path: every run of the workgroup is complete ------------------------------------------------
+        f32x4 dv[DG];
 #pragma unroll
-        for (int c = 0; c < DV; ++c) {
-            bad |= !(dv[c] <= Dmax);                 // also true for NaN, like `max_delay >= max(dt)` failing
-            same = same && (floorf(dv[c]) == kf);
+        for (int g = 0; g < DG; ++g) {
+            const f32x4 *p = (const f32x4 *)(db + base + g * DRUN);
+            dv[g] = NT ? __builtin_nontemporal_load(p) : *p;
         }
-        float out[DV];
-        if (warmup) {
-            const f32x4u x0 = *(const f32x4u *)(xb + n0), x1 = *(const f32x4u *)(xb + n0 + 4);
+        if (flag && *flag) return;                   // sticky: an earlier violation froze this state
+        float kf[DG];
+        bool same[DG];
+        f32x4u xv[DG];
+        float x4[DG];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { out[c] = x0[c]; out[4 + c] = x1[c]; }
-        } else if (same) {
-            const float *w0 = xb + (n0 - (int64_t)kf - 1);
-            const f32x4u x0 = *(const f32x4u *)w0, x1 = *(const f32x4u *)(w0 + 4);
-            const float win[DV + 1] = {x0[0], x0[1], x0[2], x0[3], x1[0], x1[1], x1[2], x1[3], w0[8]};
-#pragma unroll
-            for (int c = 0; c < DV; ++c) out[c] = delay_sample_fast(dv[c], kf, win[c + 1], win[c]);
-        } else {
-#pragma unroll
-            for (int c = 0; c < DV; ++c) out[c] = delay_sample(xb, bb, D, n0 + c, dv[c]);
+        for (int g = 0; g < DG; ++g) {               // classify, issue the tap-window loads of every run
+            kf[g] = floorf(dv[g][0]);
+            const int w = base + g * DRUN - (int)kf[g] - 1;      // first sample of the tap window
+            // one integer part for the 4 delays <=> 0 <= d_c - k < 1 (the difference is exact in that range)
+            const float t1 = dv[g][1] - kf[g], t2 = dv[g][2] - kf[g], t3 = dv[g][3] - kf[g];
+            same[g] = kf[g] >= 0.0f && kf[g] < Dmax && w >= 0 && t1 >= 0.0f && t1 < 1.0f && t2 >= 0.0f && t2 < 1.0f &&
+                      t3 >= 0.0f && t3 < 1.0f;
+            bad |= !(dv[g][0] <= Dmax) | !(dv[g][1] <= Dmax) | !(dv[g][2] <= Dmax) | !(dv[g][3] <= Dmax);   // NaN too
+            // the loads are unconditional (lanes off the fast path read a harmless in-range window), so that all of
+            // them are in flight together; warm-up mode reads the samples themselves
+            const int ws = warmup ? base + g * DRUN : (same[g] ? w : 0);
+            xv[g] = *(const f32x4u *)(xb + ws);
+            x4[g] = xb[ws + 4 < T ? ws + 4 : ws];
         }
-        *(f32x4 *)(yb + n0) = (f32x4){out[0], out[1], out[2], out[3]};
-        *(f32x4 *)(yb + n0 + 4) = (f32x4){out[4], out[5], out[6], out[7]};
+#pragma unroll
+        for (int g = 0; g < DG; ++g) {
+            const float win[DV + 1] = {xv[g][0], xv[g][1], xv[g][2], xv[g][3], x4[g]};
+            f32x4 out;
+#pragma unroll
+            for (int c = 0; c < DV; ++c) out[c] = warmup ? win[c] : delay_sample_fast(dv[g][c], kf[g], win[c + 1], win[c]);
+            if (!warmup && !same[g]) {               // rare: the general form, sample by sample
+#pragma unroll
+                for (int c = 0; c < DV; ++c) out[c] = delay_sample(xb, bb, D, base + g * DRUN + c, dv[g][c]);
+            }
+            f32x4 *q = (f32x4 *)(yb + base + g * DRUN);
+            if constexpr (NT) __builtin_nontemporal_store(out, q);
+            else *q = out;
+        }
     } else {
-        for (int c = 0; c < DV && n0 + c < T; ++c) {
-            const float dn = db[n0 + c];
-            bad |= !(dn <= Dmax);
-            yb[n0 + c] = warmup ? xb[n0 + c] : delay_sample(xb, bb, D, n0 + c, dn);
-        }
+        // ---- ragged tail / unaligned rows: sample by sample ---------------------------------------------------
+        if (flag && *flag) return;
+        for (int g = 0; g < DG; ++g)
+            for (int c = 0; c < DV; ++c) {
+                const int n = base + g * DRUN + c;
+                if (n >= T) break;
+                const float dn = db[n];
+                bad |= !(dn <= Dmax);
+                yb[n] = warmup ? xb[n] : delay_sample(xb, bb, D, n, dn);
+            }
     }
     if (flag && __any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
@@ -134,10 +171,12 @@ hipError_t launch_delay(const float *x, const float *d, float *y, int64_t B, int
                         int warmup, int32_t *err_flag, hipStream_t stream)
 {
     if (B == 0 || T == 0) return hipSuccess;
-    const int64_t tiles = (T + 256 * DV - 1) / (256 * DV);
-    if (B * tiles > 0x7fffffffLL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(delay_apply_kernel, dim3((unsigned)(B * tiles)), dim3(256), 0, stream, x, d, y, B, T, dl_state, D,
-                       warmup, err_flag);
+    if (T > 0x7fffffffLL - DRUN * DG) return hipErrorInvalidValue;      // 32-bit sample indices inside a stream
+    const int64_t tiles = (T + DRUN * DG - 1) / (DRUN * DG);
+    const int64_t nblk = 8 * tiles * ((B + 7) / 8);
+    if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(delay_apply_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, stream, x, d, y, B, (int)T, dl_state, D,
+                       warmup, err_flag, (unsigned)tiles);
     if (D > 0)
         hipLaunchKernelGGL(delay_update_kernel, dim3((unsigned)B), dim3(DU_THREADS), 0, stream, x, dl_state, T, D, err_flag);
     return hipGetLastError();

@@ -857,7 +857,7 @@ def test_c_abi_from_a_plain_cpp_process(ntm, tmp_path):
     r = subprocess.run([exe, wfile, str(tmp_path / "x.f32"), str(B), str(T), str(tmp_path / "y.f32"), str(tmp_path / "h.f32")],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
-    assert "only hidden size 64" in r.stdout                       # the refusal message of the error-path call
+    assert "8, 16, 32 and 64 are compiled" in r.stdout            # the refusal message of the error-path call
     y = np.fromfile(str(tmp_path / "y.f32"), np.float32).reshape(B, T)
     h = np.fromfile(str(tmp_path / "h.f32"), np.float32).reshape(B, 64)
     yo, ho = oracle.gru_forward(oracle_weights(W_G), x)

@@ -39,11 +39,11 @@ int main(int argc, char **argv)
     hipStream_t stream;
     HIP_OK(hipStreamCreate(&stream));
     const float *w_ih = dw, *w_hh = dw + 192, *b_ih = w_hh + 192 * 64, *b_hh = b_ih + 192, *w_o = b_hh + 192, *b_o = w_o + 64;
-    if (ntm_abi_version() != 1) { fprintf(stderr, "unexpected ABI version\n"); return 4; }
+    if (ntm_abi_version() != NTM_ABI_VERSION) { fprintf(stderr, "unexpected ABI version\n"); return 4; }
     int rc = ntm_gru_forward(w_ih, w_hh, b_ih, b_hh, w_o, b_o, NTM_HIDDEN, dx, dy, B, T, T, T, dh, stream);
     if (rc != NTM_OK) { fprintf(stderr, "ntm_gru_forward: %d %s\n", rc, ntm_last_error()); return 5; }
-    // error path: wrong hidden size must be refused with a message, not crash
-    if (ntm_gru_forward(w_ih, w_hh, b_ih, b_hh, w_o, b_o, 32, dx, dy, B, T, T, T, dh, stream) == NTM_OK) return 6;
+    // error path: a hidden size that is not compiled (8, 16, 32, 64 are) must be refused with a message, not crash
+    if (ntm_gru_forward(w_ih, w_hh, b_ih, b_hh, w_o, b_o, 24, dx, dy, B, T, T, T, dh, stream) == NTM_OK) return 6;
     HIP_OK(hipStreamSynchronize(stream));
     std::vector<float> y(x.size()), h((size_t)B * 64);
     HIP_OK(hipMemcpy(y.data(), dy, y.size() * sizeof(float), hipMemcpyDeviceToHost));
