@@ -52,6 +52,12 @@ def _file_id(path):
     return int(os.path.basename(path).split("_")[1])
 
 
+def sidecar_path(ifile):
+    """`trajectory<rest of the input file's name>.npy` in the input file's directory (code/utilities/utilities.py:273-275)."""
+    return os.path.join(os.path.dirname(ifile),
+                        "trajectory" + os.path.splitext(os.path.basename(ifile).split("input")[1])[0] + ".npy")
+
+
 def load_trajectory(path):
     """A `trajectory_<id>_*.npy` side-car -> dict(delay_trajectory [s], input_peaks, output_peaks).
     The reference writes a pickled dict (code/utilities/utilities.py:327-335, read back at :281-282 with
@@ -194,7 +200,6 @@ class SegmentFeeder:
             assert len(self.target_files) == len(self.input_files), "input / target file counts differ"
         else:
             self.target_files = [''] * len(self.input_files)
-        traj = {_file_id(p): p for p in glob.glob(os.path.join(search_dir, search_string, "trajectory_*.npy"))}
         self.fs = None
         self.examples = []
         self._audio = []
@@ -215,15 +220,17 @@ class SegmentFeeder:
                 t, _ = read_wav(tfile)
                 if x.shape[-1] != t.shape[-1]:
                     raise RuntimeError("Found potentially corrupt file!")
-            d = load_trajectory(traj[_file_id(ifile)]) if _file_id(ifile) in traj else None
+            # the side-car sits next to its input file under the input's own name (code/utilities/utilities.py:273-275):
+            # with subset "full" equal ids in Train/ Val/ Test/ must not pick up each other's trajectories
+            sidecar = sidecar_path(ifile)
+            d = load_trajectory(sidecar) if os.path.exists(sidecar) else None
             if d is None and analyze and t is not None and x.shape[0] > 1 and t.shape[0] > 1:
                 # stereo pair without a side-car: analyse the pilot channels as DelayAnalyzer does on first use
                 # (code/utilities/utilities.py:306-335) and cache the result next to the audio in its format
                 xi, yi, T_delay, xm, ym = analyze_delay(x[1].astype(np.float64), t[1].astype(np.float64), fs)
                 if write_sidecars:
-                    name = "trajectory" + os.path.splitext(os.path.basename(ifile).split("input")[1])[0] + ".npy"
                     try:
-                        write_sidecar(os.path.join(os.path.dirname(ifile), name), xi, yi, T_delay, xm, ym)
+                        write_sidecar(sidecar, xi, yi, T_delay, xm, ym)
                     except OSError:
                         pass                                   # read-only dataset: keep the analysis in memory
                 d = {"delay_trajectory": np.asarray(T_delay, np.float64), "input_peaks": xi.astype(np.int64),

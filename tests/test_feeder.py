@@ -139,3 +139,79 @@ def test_stereo_dataset_without_sidecars_is_analysed_and_cached(tmp_path):
     assert np.allclose(meta["delay_trajectory"].numpy(), g["T0"][20000:40000], atol=1e-8)
     f2 = SegmentFeeder(str(tmp_path / "Set"), subset="val", length=20000, analyze=False)      # from the cache
     assert abs(f2.max_delay - f.max_delay) < 1e-15 and np.array_equal(f2[1][2]["input_peaks"], meta["input_peaks"])
+
+
+# ----------------------------------------------------------------------------- pinned to the reference (golden g15)
+def rebuild_g15_tree(g, root):
+    """The dataset tree tools/make_goldens_dataset.py ran the reference's VADataset over, rebuilt from the arrays in
+    the golden file (same float32 WAVs; no side-cars: the feeder must analyse the pilot channels itself)."""
+    ds = os.path.join(root, "Toy[Set]_A")
+    os.makedirs(os.path.join(ds, "Test"))
+    os.makedirs(os.path.join(ds, "Train"))
+    fs = int(g["fs"])
+    for name in g["names"]:
+        wavfile.write(os.path.join(ds, "Test", f"input_{name}.wav"), fs, g[f"file_{name}_input"])
+        wavfile.write(os.path.join(ds, "Test", f"target_{name}.wav"), fs, g[f"file_{name}_target"])
+    n = int(g["file_train_3_other_len"])
+    wavfile.write(os.path.join(ds, "Train", "input_3_other.wav"), fs, g["file_3_first_input"][:n])
+    wavfile.write(os.path.join(ds, "Train", "target_3_other.wav"), fs, g["file_3_first_target"][:n])
+    return ds
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g15_feeder_equals_reference_vadataset(tmp_path, tag):
+    """SegmentFeeder against what the reference's VADataset returned for the same tree (code/dataset.py:174-293 slicing,
+    :348-429 items; DelayAnalyzer statistics; per-segment pulse indices; meta strings): '[' ']' in the path, ids that
+    sort as strings (input_10_ before input_3_), stereo audio + pilot, a last file that is not a whole number of
+    segments, sync > 0 (case b), a colliding id in another subset directory."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g15_vadataset.npz"))
+    ds = rebuild_g15_tree(g, str(tmp_path))
+    L, sync = int(g[f"{tag}_length"]), float(g[f"{tag}_sync"])
+    f = SegmentFeeder(ds, subset="test", length=L, sync=sync)
+    assert [os.path.basename(p) for p in f.input_files] == list(g[f"{tag}_input_files"])
+    assert len(f) == int(g[f"{tag}_n"])
+    assert [[e["idx"], e["offset"]] for e in f.examples] == g[f"{tag}_examples"].tolist()
+    mn, mean, mx = g[f"{tag}_delay_stats"]
+    assert abs(f.min_delay - mn) < 1e-12 and abs(f.mean_delay - mean) < 1e-12 and abs(f.max_delay - mx) < 1e-12
+    assert abs(f.minutes - float(g[f"{tag}_minutes"])) < 1e-12
+    for name in g["names"]:          # the feeder's own pulse analysis == the side-car the reference wrote
+        sc = np.load(os.path.join(ds, "Test", f"trajectory_{name}.npy"), allow_pickle=True).item()
+        assert np.array_equal(sc["input_peaks"], g[f"sidecar_{name}_input_peaks"])
+        assert np.array_equal(sc["output_peaks"], g[f"sidecar_{name}_output_peaks"])
+        assert np.abs(sc["delay_trajectory"] - g[f"sidecar_{name}_traj"]).max() < 1e-12
+    for i in range(len(f)):
+        x, t, meta = f[i]
+        idx, off = g[f"{tag}_examples"][i]
+        fname = os.path.basename(f.input_files[idx])[len("input_"):-len(".wav")]
+        # the generator verified that the reference's item is exactly this slice of the file pair
+        assert np.array_equal(x.numpy(), g[f"file_{fname}_input"].T[:, off:off + L])
+        assert np.array_equal(t.numpy(), g[f"file_{fname}_target"].T[:, off:off + L])
+        nin, ntg, ntr, sin_, stg, str_ = g[f"{tag}_{i}_shape_sums"]
+        assert (x.shape[-1], t.shape[-1], len(meta["delay_trajectory"])) == (nin, ntg, ntr)
+        assert abs(float(x.double().sum()) - sin_) < 1e-9 and abs(float(t.double().sum()) - stg) < 1e-9
+        assert abs(float(meta["delay_trajectory"].double().sum()) - str_) < 1e-6 * abs(str_)     # fp32 store of the trajectory
+        assert [meta["input_name"], meta["target_name"]] == list(g[f"{tag}_{i}_names"])
+        for k in ("input_peaks", "output_peaks"):
+            want = g[f"{tag}_{i}_{k}"]
+            got = meta[k]
+            assert (got is None and list(want) == [-1]) or np.array_equal(np.asarray(got), want), (i, k)
+        if f"{tag}_{i}_traj" in g.files:
+            assert np.abs(meta["delay_trajectory"].numpy() - g[f"{tag}_{i}_traj"]).max() < 1e-8
+
+
+def test_sidecar_lookup_is_by_file_name_not_by_id(tmp_path):
+    """subset "full": equal ids in Train/ and Test/ must each get their OWN trajectory side-car (the reference derives
+    the side-car path from the input file's name and directory, code/utilities/utilities.py:273-275)."""
+    root = os.path.join(str(tmp_path), "Set")
+    fs = 44100
+    rng = np.random.default_rng(3)
+    for sub, val in (("Train", 0.01), ("Test", 0.02)):
+        os.makedirs(os.path.join(root, sub))
+        a = rng.uniform(-0.3, 0.3, (6000, 2)).astype(np.float32)
+        wavfile.write(os.path.join(root, sub, "input_5_x.wav"), fs, a)
+        wavfile.write(os.path.join(root, sub, "target_5_x.wav"), fs, a)
+        np.save(os.path.join(root, sub, "trajectory_5_x.npy"), np.full(6000, val, np.float32))
+    f = SegmentFeeder(root, subset="full", length=3000, analyze=False)
+    got = {os.path.basename(os.path.dirname(f.input_files[f.examples[i]["idx"]])): float(f[i][2]["delay_trajectory"][0])
+           for i in range(len(f))}
+    assert abs(got["Train"] - 0.01) < 1e-7 and abs(got["Test"] - 0.02) < 1e-7

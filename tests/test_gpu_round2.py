@@ -106,13 +106,15 @@ def test_full_size_cfg3_4096_distinct_streams(ntm):
     assert np.abs(pre_g - preo).max() < TOL and np.abs(y_g - yo).max() < TOL
     assert np.abs(m.hidden[0, rows].cpu().numpy() - ho).max() < TOL
     assert np.abs(m.diffdel.buffer[rows, 0].cpu().numpy() - bo).max() < TOL
-    # exactness of K2 in isolation: oracle delay line on the GPU's pre_d, from the warm-start buffer
-    w = oracle_weights(W_D)
-    z = np.zeros((1, 1024), np.float32)
-    _, _, _, b1 = oracle.diffdel_forward(w, z, z, None, np.zeros((1, m.diffdel.max_delay), np.float32))
+    # exactness of K2 in isolation: the oracle's delay line on the GPU's own pre_d, starting from the GPU's own
+    # warm-start buffer (predict() builds it the same, deterministic way), must give the GPU's y bit for bit
+    buf_end = m.diffdel.buffer[rows, 0].cpu().numpy()
+    m.initialize_hidden(1, m.max_delay)
+    m.warm_start()
+    b1 = m.diffdel.buffer[:, 0].cpu().numpy()
     y_exact, b_exact = oracle.delay_forward(pre_g, ds, np.repeat(b1, len(rows), 0))
     assert np.array_equal(y_g, y_exact)
-    assert np.array_equal(m.diffdel.buffer[rows, 0].cpu().numpy(), b_exact)
+    assert np.array_equal(buf_end, b_exact)
 
 
 def test_diffdel_error_budget_where_the_3e6_comes_from(ntm):
@@ -334,3 +336,32 @@ def test_bench_spawns_its_own_ranks_on_one_gpu_over_gloo():
         assert out["checks"]["esr_vs_first_pass"] == 0.0
         assert out["scaling"] == ("strong" if "--scaling" in extra else "weak")
         assert abs(out["value"] - total * 4096 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+
+
+# ----------------------------------------------------------------------------- feeder, demodulated items (golden g15 c)
+def test_g15_feeder_demodulated_items_equal_reference(ntm, tmp_path):
+    """VADataset(demodulate=True).__getitem__ (code/dataset.py:395-408: demodulate the 2-channel target with the
+    segment's pulse indices, cut mean_delay from input / target / trajectory, restrict the pulses) reproduced by the
+    feeder with ntm_demodulate on the device: bit-identical audio, identical pulse indices and meta strings."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_feeder import rebuild_g15_tree
+    g = load("g15_vadataset.npz")
+    ds = rebuild_g15_tree(g, str(tmp_path))
+    L = int(g["c_length"])
+    f = ntm.feeder.SegmentFeeder(ds, subset="test", length=L, sync=float(g["c_sync"]), demodulate=True)
+    assert len(f) == int(g["c_n"]) and [[e["idx"], e["offset"]] for e in f.examples] == g["c_examples"].tolist()
+    checked = 0
+    for i in range(len(f)):
+        x, t, meta = f[i]
+        nin, ntg, ntr, sin_, stg, str_ = g[f"c_{i}_shape_sums"]
+        assert (x.shape[-1], t.shape[-1], len(meta["delay_trajectory"])) == (nin, ntg, ntr)
+        assert [meta["input_name"], meta["target_name"]] == list(g[f"c_{i}_names"])
+        assert np.array_equal(np.asarray(meta["input_peaks"]), g[f"c_{i}_input_peaks"])
+        assert np.array_equal(np.asarray(meta["output_peaks"]), g[f"c_{i}_output_peaks"])
+        assert abs(float(t.double().sum()) - stg) < 1e-6 * max(1.0, abs(stg))
+        if f"c_{i}_target" in g.files:
+            assert np.array_equal(x.numpy(), g[f"c_{i}_input"])
+            assert np.array_equal(t.numpy(), g[f"c_{i}_target"].astype(np.float32))
+            assert np.abs(meta["delay_trajectory"].numpy() - g[f"c_{i}_traj"]).max() < 1e-8
+            checked += 1
+    assert checked == 3
