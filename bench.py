@@ -284,7 +284,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch segments per GPU (N = 8: BASELINE configs[4]); strong: --total-batch segments over all GPUs")
     ap.add_argument("--total-batch", type=int, default=32768, help="segments of the whole job under --scaling strong")
-    ap.add_argument("--variant", default="auto", choices=["auto", "mfma2", "mfma", "valu", "f16x3"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "mfma2", "mfma4", "mfma", "valu", "f16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the opt-in f16x3 kernel leg")
     ap.add_argument("--workload", default="gru", choices=["gru", "diffdel", "tcn"],
@@ -491,7 +491,7 @@ def main():
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": peak_tflops, "unit": "TFLOP/s",
                      "frac": tflops / peak_tflops, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": {"auto": "gru_mfma2_kernel", "mfma2": "gru_mfma2_kernel", "mfma": "gru_mfma_kernel",
-                                "valu": "gru_valu_kernel", "f16x3": "gru_mfma2_kernel<f16x3>"}[a.variant],
+                                "valu": "gru_valu_kernel", "f16x3": "gru_mfma2_kernel<f16x3>", "mfma4": "gru_mfma4_kernel"}[a.variant],
                      "kernel_ms": 1e3 * kern_s, "flop_per_sample": flop_per_sample,
                      "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": hbm_gbs / PEAK_HBM_GBS, "bytes_per_sample": BYTES_PER_SAMPLE,

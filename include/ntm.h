@@ -46,6 +46,8 @@ extern "C" {
 #define NTM_GRU_MFMA2 3 /* as MFMA, own-quarter-first step order: LDS exchange hidden by MFMAs */
 #define NTM_GRU_MFMA3 5 /* exact fp32 hybrid: MFMA waves + partner VALU waves on the same SIMDs       */
 #define NTM_GRU_LAT 6   /* exact fp32, ONE stream per workgroup (K split over 4 waves): low latency, small B */
+#define NTM_GRU_MFMA4 7 /* exact fp32, ONE wavefront per 4 streams on v_mfma_f32_4x4x1_16B_f32: no barrier, no exchange
+                           between waves (h feeds the next step from the registers it was computed in, BLGP-routed) */
 #define NTM_GRU_LAT_MAX_B 1024
 #define NTM_GRU_F16X3 4 /* OPT-IN: MFMA2 with W.h as three fp16 hi/lo products, fp32 accumulate  */
 

@@ -10,9 +10,9 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NTM_LIB_PATH") or os.path.join(_HERE, "libntm.so")   # override: kernel A/B builds
 
-NTM_GRU_AUTO, NTM_GRU_MFMA, NTM_GRU_VALU, NTM_GRU_MFMA2, NTM_GRU_F16X3, NTM_GRU_MFMA3, NTM_GRU_LAT = 0, 1, 2, 3, 4, 5, 6
+NTM_GRU_AUTO, NTM_GRU_MFMA, NTM_GRU_VALU, NTM_GRU_MFMA2, NTM_GRU_F16X3, NTM_GRU_MFMA3, NTM_GRU_LAT, NTM_GRU_MFMA4 = 0, 1, 2, 3, 4, 5, 6, 7
 VARIANTS = {"auto": NTM_GRU_AUTO, "mfma": NTM_GRU_MFMA, "valu": NTM_GRU_VALU, "mfma2": NTM_GRU_MFMA2,
-            "f16x3": NTM_GRU_F16X3, "mfma3": NTM_GRU_MFMA3, "lat": NTM_GRU_LAT}
+            "f16x3": NTM_GRU_F16X3, "mfma3": NTM_GRU_MFMA3, "lat": NTM_GRU_LAT, "mfma4": NTM_GRU_MFMA4}
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64

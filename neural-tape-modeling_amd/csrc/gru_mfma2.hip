@@ -34,6 +34,9 @@ namespace ntm {
 #ifndef NTM2_NB
 #define NTM2_NB 1
 #endif
+#ifndef NTM2_ORDER
+#define NTM2_ORDER 0      // order of the three accumulator chains inside a K-step: 0 = r, n, z   1 = r, z, n
+#endif
 
 namespace m2 {
 constexpr int SG = 16;            // streams per workgroup
@@ -300,8 +303,13 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 #pragma unroll
             for (int sg = 0; sg < NB; ++sg) {
                 acc_r = mfma16x(Ar[sg], hB[sg], acc_r);
+#if NTM2_ORDER
+                acc_z = mfma16x(Az[sg], hB[sg], acc_z);
+                acc_n = mfma16x(An[sg], hB[sg], acc_n);
+#else
                 acc_n = mfma16x(An[sg], hB[sg], acc_n);
                 acc_z = mfma16x(Az[sg], hB[sg], acc_z);
+#endif
             }
         } else {
             acc_r = __builtin_amdgcn_mfma_f32_16x16x16f16(Ah[0][0], Bh[0], acc_r, 0, 0, 0);
@@ -343,8 +351,13 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 #pragma unroll
             for (int sg = NB; sg < ((ABL & 8) ? 4 : 16); ++sg) {
                 acc_r = mfma16x(Ar[sg], hB[sg], acc_r);
+#if NTM2_ORDER
+                acc_z = mfma16x(Az[sg], hB[sg], acc_z);
+                acc_n = mfma16x(An[sg], hB[sg], acc_n);
+#else
                 acc_n = mfma16x(An[sg], hB[sg], acc_n);
                 acc_z = mfma16x(Az[sg], hB[sg], acc_z);
+#endif
                 if (sg == 3) asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z));
             }
         } else {

@@ -94,6 +94,7 @@ int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, 
         case NTM_GRU_MFMA2: e = ntm::launch_gru_mfma2(a, (hipStream_t)stream); break;
         case NTM_GRU_MFMA3: e = ntm::launch_gru_mfma3(a, (hipStream_t)stream); break;
         case NTM_GRU_LAT: e = ntm::launch_gru_lat(a, (hipStream_t)stream); break;
+        case NTM_GRU_MFMA4: e = ntm::launch_gru_mfma4(a, (hipStream_t)stream); break;
         case NTM_GRU_F16X3: a.engine = 1; e = ntm::launch_gru_mfma2(a, (hipStream_t)stream); break;
         default: return fail(NTM_EINVAL, "ntm_gru_forward: unknown kernel variant");
     }

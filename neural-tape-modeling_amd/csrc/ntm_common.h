@@ -54,6 +54,7 @@ hipError_t launch_gru_valu(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_mfma3(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_lat(const GruArgs &a, hipStream_t stream);
+hipError_t launch_gru_mfma4(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_small(const GruArgs &a, int H, hipStream_t stream);   // H = 8, 16, 32
 hipError_t launch_debug_transpose(const float *in, float *out, hipStream_t stream);
 }  // namespace ntm

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 W_G = "GRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE]_BEST"
 W_D = "DiffDelGRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE_WOWFLUTTER]_BEST"
-VARIANTS = ["mfma2", "mfma", "valu", "f16x3", "mfma3", "lat"]
+VARIANTS = ["mfma2", "mfma", "valu", "f16x3", "mfma3", "lat", "mfma4"]
 
 
 @pytest.fixture(scope="module")
