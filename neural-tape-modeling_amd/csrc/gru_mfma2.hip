@@ -26,6 +26,7 @@
 //     are loaded, so sigmoid and tanh start directly with v_exp_f32 (saves 12 VALU ops per step).
 #include "ntm_common.h"
 
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -502,15 +503,25 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     }
 }
 
-template <typename K>
-static hipError_t launch_m2(K kernel, size_t smem_bytes, unsigned grid, const GruArgs &a, hipStream_t stream)
+// The dynamic-LDS attribute is per (kernel, device): set once for each and remembered (one process may drive several
+// devices; concurrent first calls at worst set it twice).  Real-time style callers issue thousands of short launches.
+template <typename K, K kernel>
+static hipError_t launch_m2(size_t smem_bytes, unsigned grid, const GruArgs &a, hipStream_t stream)
 {
-    // per launch: the attribute is per device, and one process may drive several
-    hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
+    static std::atomic<uint64_t> configured{0};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
+    const uint64_t bit = dev < 64 ? (uint64_t)1 << dev : 0;
+    if (!(configured.load(std::memory_order_relaxed) & bit) || !bit) {
+        e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes);
+        if (e != hipSuccess) return e;
+        configured.fetch_or(bit, std::memory_order_relaxed);
+    }
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), smem_bytes, stream, a);
     return hipGetLastError();
 }
+#define NTM2_LAUNCH(KERNEL, SMEM) launch_m2<decltype(&KERNEL), &KERNEL>(SMEM, grid, a, stream)
 
 hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream)
 {
@@ -521,18 +532,18 @@ hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream)
     // More stream groups than CUs: the small-LDS build lets two or three groups share a CU instead of running a
     // second round of workgroups (B = 6144: 7.1 ms instead of 7.7 per 4096 steps; B >= 8192: 0.76-0.80 of peak).
     const bool many = grid > (unsigned)device_cus();
-#define NTM2_ABL_CASE(M) case M: return launch_m2(gru_mfma2_kernel<true, false, M>, smem16, grid, a, stream);
+#define NTM2_ABL_CASE(M) case M: return NTM2_LAUNCH((gru_mfma2_kernel<true, false, M>), smem16);
     switch (a.abl) {
         NTM2_ABL_CASE(1) NTM2_ABL_CASE(2) NTM2_ABL_CASE(4) NTM2_ABL_CASE(8) NTM2_ABL_CASE(16) NTM2_ABL_CASE(32)
         NTM2_ABL_CASE(3) NTM2_ABL_CASE(7) NTM2_ABL_CASE(18) NTM2_ABL_CASE(39) NTM2_ABL_CASE(55) NTM2_ABL_CASE(63)
         default: break;
     }
-    if (a.dbg) return launch_m2(gru_mfma2_kernel<true, true>, smem16, grid, a, stream);
+    if (a.dbg) return NTM2_LAUNCH((gru_mfma2_kernel<true, true>), smem16);
     if (a.engine == 1)
-        return many ? launch_m2(gru_mfma2_kernel<true, false, 0, 1, 4>, smem4, grid, a, stream)
-                    : launch_m2(gru_mfma2_kernel<true, false, 0, 1, 16>, smem16, grid, a, stream);
-    return many ? launch_m2(gru_mfma2_kernel<true, false, 0, 0, 4>, smem4, grid, a, stream)
-                : launch_m2(gru_mfma2_kernel<true, false, 0, 0, 16>, smem16, grid, a, stream);
+        return many ? NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 1, 4>), smem4)
+                    : NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 1, 16>), smem16);
+    return many ? NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 4>), smem4)
+                : NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 16>), smem16);
 }
 
 hipError_t launch_debug_transpose(const float *in, float *out, hipStream_t stream)

@@ -147,3 +147,14 @@ def test_g14_tape_stages_host_side():
     assert np.array_equal(g["I_in"][:, :sp] + b1, g["I_rec"][:, :sp]) and np.array_equal(g["I_in"][:, sp:] + b2, g["I_rec"][:, sp:])
     assert tp.bias_phase == float(g["bias_phase_end"]) and not tp.FLAG_STARTUP
     assert np.array_equal(tp.H_play(g["M"]), g["V_play"]) and np.array_equal(tp.H_post(tp.H_play(g["M"])), g["V_out"])
+
+
+def test_step_barrier_wait_count_matches_the_disassembly():
+    """The step barrier of gru_mfma2_kernel is `s_waitcnt lgkmcnt(1); s_barrier` in inline asm: valid only while exactly
+    one LDS/SMEM op (the y-partial ds_write_b32) sits between the h-exchange write and the barrier.  The compiler is not
+    bound by that, so the disassembly of every product instantiation is checked (tools/check_barrier_asm.py)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_barrier_asm.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

@@ -218,3 +218,22 @@ def test_g16_diffdel_hidden_16():
     assert np.abs(pre - g["dd_pre_d"][:, 0, :]).max() < GRU_TOL
     assert np.abs(y - g["dd_y"][:, 0, :]).max() < GRU_TOL
     assert np.abs(buf - g["dd_buffer"][:, 0, :]).max() < GRU_TOL and np.abs(h - g["dd_hidden"][0]).max() < GRU_TOL
+
+
+def test_oracle_under_address_and_ub_sanitizers():
+    """SURVEY.md 5 asks for a CPU sanitizer build of the restatement: `make -C oracle asan` (ASan + UBSan), every entry
+    point exercised in a child process with the sanitizer runtime preloaded (tests/asan_driver.py)."""
+    import os
+    import subprocess
+    import sys
+    from helpers import ROOT
+    odir = os.path.join(ROOT, "oracle")
+    subprocess.run(["make", "-s", "-C", odir, "asan"], check=True)
+    libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True, check=True).stdout.strip()
+    env = dict(os.environ, NTM_ORACLE_LIB=os.path.join(odir, "libntm_oracle_asan.so"), LD_PRELOAD=libasan,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+               PYTHONPATH=os.pathsep.join([ROOT, os.path.join(ROOT, "tests")]))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "asan_driver.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "ASAN_DRIVER_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]

@@ -26,8 +26,10 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     allv = [x for v in vals.values() for x in v]
     # the largest launches are the workload; small ones (warm-start with B = 1) are left out of the mean
     big = [x for x in allv if x > 0.5 * max(allv)] if allv else []
-    out[c + "_KB_mean_of_full_size_launches"] = sum(big) / len(big) if big else None
-f, w = out["FETCH_SIZE_KB_mean_of_full_size_launches"], out["WRITE_SIZE_KB_mean_of_full_size_launches"]
+    # median: a launch that ran while another kernel was still on a side stream (bench.py overlaps the ESR pass of the
+    # previous step) also counts that kernel's bytes in its window
+    out[c + "_KB_median_of_full_size_launches"] = sorted(big)[len(big) // 2] if big else None
+f, w = out["FETCH_SIZE_KB_median_of_full_size_launches"], out["WRITE_SIZE_KB_median_of_full_size_launches"]
 if f is not None and w is not None:
     out["hbm_bytes_per_launch_corrected"] = (2.0 * f + w) * 1024.0
     out["algorithmic_bytes_per_launch"] = alg
