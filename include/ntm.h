@@ -39,7 +39,9 @@ extern "C" {
                          default 16, code/train.py:50) run on one wave-per-64/H-streams kernel, any variant
                          among AUTO / LAT / VALU.                                                               */
 
-/* GRU kernel variants for ntm_gru_forward_ex:                              */
+/* GRU kernel variants.  ntm_gru_forward_ex of libntm.so (the product) accepts NTM_GRU_AUTO, _MFMA2,
+ * _LAT and the opt-in _F16X3; the others are LABORATORY kernels -- older or experimental exact-fp32 implementations
+ * kept as independent checks and as measured dead ends -- compiled into libntm_lab.so only (include/ntm_lab.h).  */
 #define NTM_GRU_AUTO 0  /* NTM_GRU_MFMA2, or NTM_GRU_LAT when B <= NTM_GRU_LAT_MAX_B         */
 #define NTM_GRU_MFMA 1  /* 16 streams / workgroup, 4 waves, v_mfma_f32_16x16x4_f32, h in LDS */
 #define NTM_GRU_VALU 2  /* 2 streams / wavefront, W_hh in VGPRs, h broadcast through LDS     */
@@ -80,27 +82,6 @@ int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, 
                        const float *w_o, const float *b_o, int H, const float *x, float *y,
                        int64_t B, int64_t T, int64_t x_stride_b, int64_t y_stride_b,
                        float *h_state, int variant, void *stream);
-
-/*
- * DIAGNOSTIC ONLY (never timed): an MFMA kernel (variant NTM_GRU_MFMA or NTM_GRU_MFMA2) with
- * s_memtime stamps.  stamps[(B+15)/16][4][6] (device, uint64) receives per-wave cycle sums of six
- * step segments over the whole launch (segment names: tools/stamp_profile.py).  Outputs are the
- * same as ntm_gru_forward.
- */
-int ntm_debug_gru_stamps(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
-                         const float *w_o, const float *b_o, const float *x, float *y, int64_t B,
-                         int64_t T, float *h_state, uint64_t *stamps, int variant, void *stream);
-
-/* DIAGNOSTIC ONLY (wrong results on purpose, for timing ablations of the MFMA2 kernel): mask bits
- * 1 no gate math, 2 no LDS exchange of h, 4 no head partial, 8 own-quarter MFMAs only, 16 no barrier,
- * 32 no tile housekeeping; only the combinations compiled in gru_mfma2.hip are accepted. */
-int ntm_debug_gru_ablate(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
-                         const float *w_o, const float *b_o, const float *x, float *y, int64_t B,
-                         int64_t T, float *h_state, int mask, void *stream);
-
-/* DIAGNOSTIC ONLY: the in-register 4x4 lane-group transpose used by the MFMA2 kernel, applied to one
- * 256-thread block: in/out [256][4] floats (device). */
-int ntm_debug_transpose4(const float *in, float *out, void *stream);
 
 /*
  * Replaces TimeVaryingDelayLine.forward(x, dt, warmup), code/model.py:269-320.
@@ -174,6 +155,20 @@ int ntm_stft_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t 
  */
 int ntm_spec_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int n_fft, int hop,
                   int win_length, float log_floor, int chunks, double *out, void *stream);
+
+/*
+ * The two MEL entries of the same bundle (code/evaluation.py:86-92): the power spectrogram of
+ * `TimeFreqConverter(n_fft = 2048, hop 512)` projected on the mel basis `librosa.filters.mel(sr, n_fft, 160)`
+ * (code/utilities/utilities.py:639-646, :666) inside the transform kernel, then
+ *   out[..0..3] = sum |mel_y - mel_t| | sum |log10 max(mel_y, log_floor) - log10 max(mel_t, log_floor)| | sum mel_t | sum mel_y
+ * in the partial-row layout of ntm_stft_sums.  The filter bank comes in row-compressed form (device arrays): filter m
+ * has weights mel_w[mel_start[m] .. mel_start[m+1]) on the bins mel_first[m], mel_first[m] + 1, ...  (host helper:
+ * ntm_amd.utilities.mel_filterbank_sparse; librosa is un-vendored and absent: published algorithm, parity unpinned).
+ * n_fft in {1024, 2048}; there are (1 + (T-skip)/hop) * n_mels cells per stream.
+ */
+int ntm_mel_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int n_fft, int hop, int win_length,
+                 float log_floor, int chunks, int n_mels, const int32_t *mel_first, const int32_t *mel_start,
+                 const float *mel_w, double *out, void *stream);
 
 /*
  * "Next" row N2 plumbing: pitched asynchronous copy between (pinned) host memory and the device, rows x

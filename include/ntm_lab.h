@@ -1,0 +1,58 @@
+/*
+ * ntm_lab.h -- C ABI of libntm_lab.so: the LABORATORY beside the product library libntm.so (include/ntm.h).
+ *
+ * Older and experimental exact-fp32 GRU-HS[64] kernels (kept as independent implementations for the parity tests and
+ * as documented, measured dead ends: DESIGN.md) and the diagnostic builds of the product kernel.  Nothing on the
+ * product path loads this library; same pointer / stream / error conventions as ntm.h.
+ */
+#ifndef NTM_LAB_H
+#define NTM_LAB_H
+
+#include "ntm.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Thread-local message for the last failing laboratory call on this thread. */
+const char *ntm_lab_last_error(void);
+
+/*
+ * Same contract as ntm_gru_forward_ex (code/model.py:81-82), for variant in
+ *   NTM_GRU_MFMA   first matrix-pipe kernel (natural K order, LDS exchange exposed)
+ *   NTM_GRU_VALU   one wavefront per two streams on v_fma_f32 (north_star's first idea)
+ *   NTM_GRU_MFMA3  MFMA waves + partner VALU waves on the same SIMDs (negative result)
+ *   NTM_GRU_MFMA4  one wavefront per 4 streams on v_mfma_f32_4x4x1_16B_f32, no barrier (negative result: the chip
+ *                  clocks down under 4x4x1 MFMAs)
+ * H must be 64.
+ */
+int ntm_lab_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                        const float *w_o, const float *b_o, int H, const float *x, float *y,
+                        int64_t B, int64_t T, int64_t x_stride_b, int64_t y_stride_b,
+                        float *h_state, int variant, void *stream);
+
+/*
+ * DIAGNOSTIC ONLY (never timed): an MFMA kernel (variant NTM_GRU_MFMA or NTM_GRU_MFMA2) with
+ * s_memtime stamps.  stamps[(B+15)/16][4][6] (device, uint64) receives per-wave cycle sums of six
+ * step segments over the whole launch (segment names: tools/stamp_profile.py).  Outputs are the
+ * same as ntm_gru_forward.
+ */
+int ntm_debug_gru_stamps(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                         const float *w_o, const float *b_o, const float *x, float *y, int64_t B,
+                         int64_t T, float *h_state, uint64_t *stamps, int variant, void *stream);
+
+/* DIAGNOSTIC ONLY (wrong results on purpose, for timing ablations of the MFMA2 kernel): mask bits
+ * 1 no gate math, 2 no LDS exchange of h, 4 no head partial, 8 own-quarter MFMAs only, 16 no barrier,
+ * 32 no tile housekeeping; only the combinations compiled in gru_mfma2.hip are accepted. */
+int ntm_debug_gru_ablate(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                         const float *w_o, const float *b_o, const float *x, float *y, int64_t B,
+                         int64_t T, float *h_state, int mask, void *stream);
+
+/* DIAGNOSTIC ONLY: the in-register 4x4 lane-group transpose used by the MFMA2 kernel, applied to one
+ * 256-thread block: in/out [256][4] floats (device). */
+int ntm_debug_transpose4(const float *in, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NTM_LAB_H */

@@ -9,6 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NTM_LIB_PATH") or os.path.join(_HERE, "libntm.so")   # override: kernel A/B builds
+LAB_PATH = os.environ.get("NTM_LAB_PATH") or os.path.join(_HERE, "libntm_lab.so")   # laboratory kernels + diagnostics
 
 NTM_GRU_AUTO, NTM_GRU_MFMA, NTM_GRU_VALU, NTM_GRU_MFMA2, NTM_GRU_F16X3, NTM_GRU_MFMA3, NTM_GRU_LAT, NTM_GRU_MFMA4 = 0, 1, 2, 3, 4, 5, 6, 7
 VARIANTS = {"auto": NTM_GRU_AUTO, "mfma": NTM_GRU_MFMA, "valu": NTM_GRU_VALU, "mfma2": NTM_GRU_MFMA2,
@@ -23,9 +24,6 @@ _SIGNATURES = {
     "ntm_last_error": (ctypes.c_char_p, []),
     "ntm_gru_forward": (_int, [_vp] * 6 + [_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "ntm_gru_forward_ex": (_int, [_vp] * 6 + [_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp]),
-    "ntm_debug_gru_stamps": (_int, [_vp] * 6 + [_vp, _vp, _i64, _i64, _vp, _vp, _int, _vp]),
-    "ntm_debug_transpose4": (_int, [_vp, _vp, _vp]),
-    "ntm_debug_gru_ablate": (_int, [_vp] * 6 + [_vp, _vp, _i64, _i64, _vp, _int, _vp]),
     "ntm_delay_forward": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _int, _int, _vp, _vp]),
     "ntm_diffdel_gru_forward": (_int, [_vp] * 5 + [_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _int,
                                                    _vp, _vp]),
@@ -34,6 +32,7 @@ _SIGNATURES = {
     "ntm_esr_dcpre_sums": (_int, [_vp, _vp, _i64, _i64, _i64, ctypes.c_float, _vp, _vp]),
     "ntm_spec_sums": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _int, _int, ctypes.c_float, _int, _vp, _vp]),
     "ntm_stft_sums": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _int, _int, ctypes.c_float, _int, _vp, _vp]),
+    "ntm_mel_sums": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _int, _int, ctypes.c_float, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "ntm_copy2d_async": (_int, [_vp, _i64, _vp, _i64, _i64, _i64, _int, _vp]),
     "ntm_demodulate": (_int, [_vp, _vp, _int, _i64, _vp, _int, _i64, _i64, _vp, _vp]),
     "ntm_tape_record_field": (_int, [_vp, _vp, _vp, _i64, _i64, ctypes.c_double, ctypes.c_double, _vp]),
@@ -42,7 +41,18 @@ _SIGNATURES = {
     "ntm_tcn_scratch_floats": (_i64, [_i64, _i64, _int]),
 }
 
+# include/ntm_lab.h: libntm_lab.so (older / experimental GRU kernels, diagnostic builds) -- tests and tools only
+_LAB_SIGNATURES = {
+    "ntm_lab_last_error": (ctypes.c_char_p, []),
+    "ntm_lab_gru_forward": (_int, [_vp] * 6 + [_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp]),
+    "ntm_debug_gru_stamps": (_int, [_vp] * 6 + [_vp, _vp, _i64, _i64, _vp, _vp, _int, _vp]),
+    "ntm_debug_transpose4": (_int, [_vp, _vp, _vp]),
+    "ntm_debug_gru_ablate": (_int, [_vp] * 6 + [_vp, _vp, _i64, _i64, _vp, _int, _vp]),
+}
+LAB_VARIANTS = ("mfma", "valu", "mfma3", "mfma4")
+
 _lib = None
+_lab = None
 ABI_VERSION = 2          # include/ntm.h NTM_ABI_VERSION this binding was written against
 HIDDEN_SIZES = (8, 16, 32, 64)
 
@@ -73,9 +83,31 @@ def lib():
     return _lib
 
 
-def check(rc, what):
+def lab():
+    """libntm_lab.so: the laboratory kernels (kernel_variant in LAB_VARIANTS) and the diagnostic entry points.  The
+    product path (kernel_variant "auto" / "mfma2" / "lat" / "f16x3") never loads it."""
+    global _lab
+    if _lab is None:
+        if not os.path.exists(LAB_PATH):
+            raise NtmError(f"{LAB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}`")
+        handle = ctypes.CDLL(LAB_PATH)
+        for name, (res, args) in _LAB_SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        _lab = handle
+    return _lab
+
+
+def gru_forward_fn(variant_name, hidden_size=64):
+    """-> (entry point with ntm_gru_forward_ex's signature, error-message getter) for a kernel_variant name."""
+    if variant_name in LAB_VARIANTS and hidden_size == 64:
+        return lab().ntm_lab_gru_forward, lab().ntm_lab_last_error
+    return lib().ntm_gru_forward_ex, lib().ntm_last_error
+
+
+def check(rc, what, last_error=None):
     if rc != 0:
-        raise NtmError(f"{what} failed ({rc}): {lib().ntm_last_error().decode()}")
+        raise NtmError(f"{what} failed ({rc}): {(last_error or lib().ntm_last_error)().decode()}")
 
 
 def ptr(t):

@@ -1,7 +1,8 @@
 // "Next" row N3: DelayAnalyzer.demodulate, code/utilities/utilities.py:408-465 -- undo the time-varying delay of a
 // (C, N) recording from the pulse indices of its pilot train.  Two piecewise-linear maps, both evaluated with
-// the formulas of scipy.interpolate.interp1d(kind='linear') in fp64 so that the result matches the reference's
-// numpy/scipy code to the last bit before the final fp32 store:
+// the formulas of scipy.interpolate.interp1d(kind='linear') -- fp64, with the audio knot values kept in float32 as
+// scipy keeps them -- so that the result matches the reference's numpy/scipy code to the last bit before the final
+// fp32 store:
 //   y_hat[j] = f(j),  f through the knots (y_idx[i] -> y_idx[0] + i*period), extrapolated          (:441-447)
 //   dem[t]   = g(t),  g through the knots (y_hat[j] -> x[:, j]); below the first knot x[:, 0], above the
 //              last knot x[:, 1] (the reference passes fill_value=(output[:, 0], output[:, 1]))      (:450-455)
@@ -58,9 +59,12 @@ __global__ __launch_bounds__(256) void demod_apply_kernel(const float *x, float 
     const int64_t lo = hi - 1;
     const double x_lo = y_hat[lo], dx = y_hat[hi] - x_lo, dt = tv - x_lo;
     for (int c = 0; c < C; ++c) {
-        const double v_lo = (double)x[c * N + lo], v_hi = (double)x[c * N + hi];
-        const double slope = (v_hi - v_lo) / dx;
-        out[c * N + tp] = (float)(slope * dt + v_lo);
+        // float32 knot values, as the reference's caller passes them (code/dataset.py:397): scipy's interp1d keeps
+        // that dtype, so the difference is rounded to float32 before the float64 slope is formed
+        const float v_lo = x[c * N + lo], v_hi = x[c * N + hi];
+        const float dv = v_hi - v_lo;
+        const double slope = (double)dv / dx;
+        out[c * N + tp] = (float)(slope * dt + (double)v_lo);
     }
 }
 

@@ -78,6 +78,7 @@ __device__ __forceinline__ void transpose_groups4(float (&r)[4])
     r[2] = __builtin_bit_cast(float, a2); r[3] = __builtin_bit_cast(float, a3);
 }
 
+#ifdef NTM_LAB
 __global__ __launch_bounds__(256) void debug_transpose_kernel(const float *in, float *out)
 {
     float r[4];
@@ -85,6 +86,7 @@ __global__ __launch_bounds__(256) void debug_transpose_kernel(const float *in, f
     transpose_groups4(r);
     for (int v = 0; v < 4; ++v) out[threadIdx.x * 4 + v] = r[v];
 }
+#endif
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -532,6 +534,9 @@ hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream)
     // More stream groups than CUs: the small-LDS build lets two or three groups share a CU instead of running a
     // second round of workgroups (B = 6144: 7.1 ms instead of 7.7 per 4096 steps; B >= 8192: 0.76-0.80 of peak).
     const bool many = grid > (unsigned)device_cus();
+#ifdef NTM_LAB
+    // libntm_lab.so only: the diagnostic instantiations (s_memtime stamps, timing ablations) behind
+    // ntm_debug_gru_stamps / ntm_debug_gru_ablate -- never compiled into the product library
 #define NTM2_ABL_CASE(M) case M: return NTM2_LAUNCH((gru_mfma2_kernel<true, false, M>), smem16);
     switch (a.abl) {
         NTM2_ABL_CASE(1) NTM2_ABL_CASE(2) NTM2_ABL_CASE(4) NTM2_ABL_CASE(8) NTM2_ABL_CASE(16) NTM2_ABL_CASE(32)
@@ -539,6 +544,9 @@ hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream)
         default: break;
     }
     if (a.dbg) return NTM2_LAUNCH((gru_mfma2_kernel<true, true>), smem16);
+#else
+    if (a.abl || a.dbg) return hipErrorInvalidValue;      // diagnostics live in libntm_lab.so
+#endif
     if (a.engine == 1)
         return many ? NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 1, 4>), smem4)
                     : NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 1, 16>), smem16);
@@ -546,10 +554,12 @@ hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream)
                 : NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 16>), smem16);
 }
 
+#ifdef NTM_LAB
 hipError_t launch_debug_transpose(const float *in, float *out, hipStream_t stream)
 {
     hipLaunchKernelGGL(debug_transpose_kernel, dim3(1), dim3(256), 0, stream, in, out);
     return hipGetLastError();
 }
+#endif
 
 }  // namespace ntm

@@ -15,7 +15,8 @@ int esr_default_splits(int64_t B, int64_t T, int64_t skip);
 hipError_t launch_esr_dcpre(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, float R, double *out,
                             hipStream_t stream);
 hipError_t launch_stft_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int n_fft, int hop,
-                            int win, float eps, int chunks, int mode, double *out, hipStream_t stream);
+                            int win, float eps, int chunks, int mode, double *out, hipStream_t stream, int n_mels = 0,
+                            const int *mel_first = nullptr, const int *mel_start = nullptr, const float *mel_w = nullptr);
 hipError_t launch_demodulate(const float *x, float *out, int C, int64_t N, const int64_t *y_idx, int P, int64_t period,
                              int64_t shift, double *scratch, hipStream_t stream);
 hipError_t launch_tape_record_field(const double *I, const double *bias, double *H, int64_t B, int64_t N, double gain,
@@ -89,13 +90,12 @@ int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, 
         } else variant = NTM_GRU_MFMA2;
     }
     switch (variant) {
-        case NTM_GRU_MFMA: e = ntm::launch_gru_mfma(a, (hipStream_t)stream); break;
-        case NTM_GRU_VALU: e = ntm::launch_gru_valu(a, (hipStream_t)stream); break;
         case NTM_GRU_MFMA2: e = ntm::launch_gru_mfma2(a, (hipStream_t)stream); break;
-        case NTM_GRU_MFMA3: e = ntm::launch_gru_mfma3(a, (hipStream_t)stream); break;
         case NTM_GRU_LAT: e = ntm::launch_gru_lat(a, (hipStream_t)stream); break;
-        case NTM_GRU_MFMA4: e = ntm::launch_gru_mfma4(a, (hipStream_t)stream); break;
         case NTM_GRU_F16X3: a.engine = 1; e = ntm::launch_gru_mfma2(a, (hipStream_t)stream); break;
+        case NTM_GRU_MFMA: case NTM_GRU_VALU: case NTM_GRU_MFMA3: case NTM_GRU_MFMA4:
+            return fail(NTM_EINVAL, "ntm_gru_forward: laboratory kernel variant -- those live in libntm_lab.so "
+                                    "(ntm_lab_gru_forward, include/ntm_lab.h), not in the product library");
         default: return fail(NTM_EINVAL, "ntm_gru_forward: unknown kernel variant");
     }
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_gru_forward");
@@ -107,34 +107,6 @@ int ntm_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih, con
 {
     return ntm_gru_forward_ex(w_ih, w_hh, b_ih, b_hh, w_o, b_o, H, x, y, B, T, x_stride_b, y_stride_b, h_state,
                               NTM_GRU_AUTO, stream);
-}
-
-int ntm_debug_gru_stamps(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *w_o,
-                         const float *b_o, const float *x, float *y, int64_t B, int64_t T, float *h_state,
-                         uint64_t *stamps, int variant, void *stream)
-{
-    if (!stamps || !x || !y || B <= 0 || T <= 0) return fail(NTM_EINVAL, "ntm_debug_gru_stamps: bad argument");
-    ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, T, T, (unsigned long long *)stamps, 0, 0};
-    hipError_t e = variant == NTM_GRU_MFMA ? ntm::launch_gru_mfma(a, (hipStream_t)stream)
-                                           : ntm::launch_gru_mfma2(a, (hipStream_t)stream);
-    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_debug_gru_stamps");
-}
-
-int ntm_debug_gru_ablate(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *w_o,
-                         const float *b_o, const float *x, float *y, int64_t B, int64_t T, float *h_state, int mask,
-                         void *stream)
-{
-    if (!x || !y || B <= 0 || T <= 0 || mask <= 0) return fail(NTM_EINVAL, "ntm_debug_gru_ablate: bad argument");
-    ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, T, T, nullptr, mask, 0};
-    hipError_t e = ntm::launch_gru_mfma2(a, (hipStream_t)stream);
-    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_debug_gru_ablate");
-}
-
-int ntm_debug_transpose4(const float *in, float *out, void *stream)
-{
-    if (!in || !out) return fail(NTM_EINVAL, "ntm_debug_transpose4: null pointer");
-    hipError_t e = ntm::launch_debug_transpose(in, out, (hipStream_t)stream);
-    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_debug_transpose4");
 }
 
 int ntm_delay_forward(const float *x, const float *d, float *y, int64_t B, int64_t T, float *dl_state, int D,
@@ -183,7 +155,8 @@ int ntm_esr_dcpre_sums(const float *y, const float *t, int64_t B, int64_t T, int
 }
 
 static int stft_common(const char *who, const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int n_fft, int hop,
-                       int win_length, float floor_, int chunks, int mode, double *out, void *stream)
+                       int win_length, float floor_, int chunks, int mode, double *out, void *stream, int n_mels = 0,
+                       const int *mel_first = nullptr, const int *mel_start = nullptr, const float *mel_w = nullptr)
 {
     const std::string w(who);
     if (B < 0 || T < 0 || skip < 0 || skip > T) return fail(NTM_EINVAL, w + ": bad size");
@@ -196,7 +169,8 @@ static int stft_common(const char *who, const float *y, const float *t, int64_t 
     if (T - skip <= n_fft / 2) return fail(NTM_EINVAL, w + ": reflect padding needs T - skip > n_fft/2");
     if (T - skip > 0x7fffffff - 4096) return fail(NTM_EINVAL, w + ": T - skip must be below 2^31 - 4096");
     if (!y || !t || !out) return fail(NTM_EINVAL, w + ": null pointer");
-    hipError_t e = ntm::launch_stft_sums(y, t, B, T, skip, n_fft, hop, win_length, floor_, chunks, mode, out, (hipStream_t)stream);
+    hipError_t e = ntm::launch_stft_sums(y, t, B, T, skip, n_fft, hop, win_length, floor_, chunks, mode, out, (hipStream_t)stream,
+                                         n_mels, mel_first, mel_start, mel_w);
     return e == hipSuccess ? NTM_OK : hip_fail(e, who);
 }
 
@@ -210,6 +184,17 @@ int ntm_spec_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t 
                   float log_floor, int chunks, double *out, void *stream)
 {
     return stft_common("ntm_spec_sums", y, t, B, T, skip, n_fft, hop, win_length, log_floor, chunks, 1, out, stream);
+}
+
+int ntm_mel_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int n_fft, int hop, int win_length,
+                 float log_floor, int chunks, int n_mels, const int32_t *mel_first, const int32_t *mel_start, const float *mel_w,
+                 double *out, void *stream)
+{
+    if (n_fft != 1024 && n_fft != 2048) return fail(NTM_EINVAL, "ntm_mel_sums: n_fft must be 1024 or 2048");
+    if (n_mels < 1 || n_mels > 4096) return fail(NTM_EINVAL, "ntm_mel_sums: bad n_mels");
+    if (B > 0 && (!mel_first || !mel_start || !mel_w)) return fail(NTM_EINVAL, "ntm_mel_sums: null filter-bank pointer");
+    return stft_common("ntm_mel_sums", y, t, B, T, skip, n_fft, hop, win_length, log_floor, chunks, 2, out, stream, n_mels,
+                       mel_first, mel_start, mel_w);
 }
 
 int ntm_copy2d_async(void *dst, int64_t dst_pitch_bytes, const void *src, int64_t src_pitch_bytes, int64_t width_bytes,

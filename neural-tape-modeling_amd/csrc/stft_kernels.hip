@@ -30,6 +30,11 @@ struct StftArgs {
     int hop, win, chunks, frames_per_chunk, n_frames, mode;
     float eps;
     double *out;
+    // mode 2 (mel): row-compressed mel filter bank (device): filter m = mel_w[mel_start[m] .. mel_start[m+1]) on the
+    // bins mel_first[m] ...
+    const int *mel_first, *mel_start;
+    const float *mel_w;
+    int n_mels;
 };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -280,17 +285,57 @@ __global__ __launch_bounds__(256, (LOG2N <= 10 ? 2 : 1)) void stft_sums_kernel(S
                 s3 += py0;
             }
         };
-        if (live) {
+        if constexpr (MODE != 2) {
+            if (live) {
 #pragma unroll
-            for (int i = 0; i < P / 2; ++i) bin(sl + SUB * i);
-            if (sl == 0) bin(N / 2);
+                for (int i = 0; i < P / 2; ++i) bin(sl + SUB * i);
+                if (sl == 0) bin(N / 2);
+            }
+        } else {
+            // mel entries of code/evaluation.py:86-92: mel = mel_basis @ power spectrogram (code/utilities/utilities.py:
+            // 666), per frame.  The two power spectra (N/2 + 1 bins each) take the frame's exchange buffer over -- every
+            // lane first reads its bins out of it -- and lane m then walks the bins of filters m, m + 64, ... (a triangle
+            // spans 2 .. ~50 bins).  One frame per wave here (n_fft >= 256).
+            static_assert(MODE != 2 || FPW == 1, "mel mode: one frame per wave");
+            float py_[P / 2], pt_[P / 2], pyn = 0.0f, ptn = 0.0f;
+            auto power = [&](int k, float &py0, float &pt0) {
+                const f2 zk = buf[padi(k)], zn = buf[padi((N - k) & (N - 1))];
+                const float yr = 0.5f * (zk.x + zn.x), yi = 0.5f * (zk.y - zn.y);
+                const float tr = 0.5f * (zk.y + zn.y), ti = 0.5f * (zn.x - zk.x);
+                py0 = yr * yr + yi * yi;
+                pt0 = tr * tr + ti * ti;
+            };
+#pragma unroll
+            for (int i = 0; i < P / 2; ++i) power(sl + SUB * i, py_[i], pt_[i]);
+            if (sl == 0) power(N / 2, pyn, ptn);
+            wave_lds_fence();                                   // every lane has read its bins: the buffer is free
+            float *pw = reinterpret_cast<float *>(buf);         // [0 .. N/2] P_y, [N/2 + 1 .. N + 1] P_t
+#pragma unroll
+            for (int i = 0; i < P / 2; ++i) { pw[sl + SUB * i] = py_[i]; pw[N / 2 + 1 + sl + SUB * i] = pt_[i]; }
+            if (sl == 0) { pw[N / 2] = pyn; pw[N + 1] = ptn; }
+            wave_lds_fence();
+            if (live) {
+                for (int m = sl; m < a.n_mels; m += 64) {
+                    const int b0 = a.mel_first[m], w0 = a.mel_start[m], nw = a.mel_start[m + 1] - w0;
+                    float my = 0.0f, mt = 0.0f;
+                    for (int q = 0; q < nw; ++q) {
+                        const float wq = a.mel_w[w0 + q];
+                        my = __builtin_fmaf(wq, pw[b0 + q], my);
+                        mt = __builtin_fmaf(wq, pw[N / 2 + 1 + b0 + q], mt);
+                    }
+                    s0 += fabsf(my - mt);
+                    s1 += fabsf(__builtin_amdgcn_logf(fmaxf(my, a.eps)) - __builtin_amdgcn_logf(fmaxf(mt, a.eps)));
+                    s2 += mt;
+                    s3 += my;
+                }
+            }
         }
         acc[0] += s0; acc[1] += s1; acc[2] += s2; acc[3] += s3;
         wave_lds_fence();
     }
     // mode 0: |ln mag_y - ln mag_t| = (ln 2 / 2) |log2 p_y - log2 p_t|;  mode 1: log10 = log10(2) log2
     if constexpr (MODE == 0) acc[2] *= 0.34657359027997264;
-    else acc[1] *= 0.30102999566398120;
+    else acc[1] *= 0.30102999566398120;                       // modes 1 and 2: log10 = log10(2) log2
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         double s = acc[c];
@@ -315,14 +360,20 @@ static hipError_t launch_mode(const StftArgs &a, hipStream_t stream)
 template <int LOG2N>
 static hipError_t launch_one(const StftArgs &a, hipStream_t stream)
 {
+    if constexpr (LOG2N >= 10) {             // the mel projection is compiled for the frame sizes it is used with
+        if (a.mode == 2) return launch_mode<LOG2N, 2>(a, stream);
+    }
+    if (a.mode == 2) return hipErrorInvalidValue;
     return a.mode == 0 ? launch_mode<LOG2N, 0>(a, stream) : launch_mode<LOG2N, 1>(a, stream);
 }
 
 hipError_t launch_stft_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int n_fft, int hop,
-                            int win, float eps, int chunks, int mode, double *out, hipStream_t stream)
+                            int win, float eps, int chunks, int mode, double *out, hipStream_t stream, int n_mels,
+                            const int *mel_first, const int *mel_start, const float *mel_w)
 {
     StftArgs a;
     a.mode = mode;
+    a.n_mels = n_mels; a.mel_first = mel_first; a.mel_start = mel_start; a.mel_w = mel_w;
     a.y = y; a.t = t; a.B = B; a.T = T; a.skip = skip; a.hop = hop; a.win = win; a.chunks = chunks; a.eps = eps; a.out = out;
     a.n_frames = (int)(1 + (T - skip) / hop);
     a.frames_per_chunk = (a.n_frames + chunks - 1) / chunks;

@@ -68,7 +68,9 @@ def _as_bt(x, what):
 class _GRUHead(torch.nn.Module):
     """GRU(1,H) + Linear(H,1[,bias]) state and launch logic shared by RNN and DiffDelRNN."""
 
-    kernel_variant = "auto"      # "auto" | "mfma2" | "lat" | "f16x3" | "mfma" | "valu" | "mfma3"  (include/ntm.h NTM_GRU_*)
+    # product kernels (libntm.so): "auto" | "mfma2" | "lat" | "f16x3" (opt-in);  laboratory kernels for A/B and as
+    # independent implementations in the tests (libntm_lab.so): "mfma" | "valu" | "mfma3" | "mfma4"  (NTM_GRU_*)
+    kernel_variant = "auto"
 
     def _init_net(self, input_size, hidden_size, output_size, skip, head_bias):
         if input_size != 1 or output_size != 1:
@@ -98,11 +100,11 @@ class _GRUHead(torch.nn.Module):
         h = self._hidden_for(B, xbt.device)
         y = torch.empty_like(xbt)
         g, o = self.GRU, self.output
-        rc = _lib.lib().ntm_gru_forward_ex(
-            ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0), ptr(o.weight),
-            ptr(o.bias), self.hidden_size, ptr(xbt), ptr(y), B, T, T, T, ptr(h),
-            _lib.VARIANTS[self.kernel_variant], _lib.current_stream())
-        _lib.check(rc, "ntm_gru_forward")
+        fn, err = _lib.gru_forward_fn(self.kernel_variant, self.hidden_size)
+        rc = fn(ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0), ptr(o.weight),
+                ptr(o.bias), self.hidden_size, ptr(xbt), ptr(y), B, T, T, T, ptr(h),
+                _lib.VARIANTS[self.kernel_variant], _lib.current_stream())
+        _lib.check(rc, "ntm_gru_forward", err)
         self.hidden = h
         return y
 
@@ -120,11 +122,11 @@ class _GRUHead(torch.nn.Module):
         B, T = x2d.shape
         h = self._hidden_for(B, x2d.device)
         g, o = self.GRU, self.output
-        rc = _lib.lib().ntm_gru_forward_ex(
-            ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0), ptr(o.weight),
-            ptr(o.bias), self.hidden_size, ptr(x2d), ptr(y2d), B, T, max(x2d.stride(0), T), max(y2d.stride(0), T), ptr(h),
-            _lib.VARIANTS[self.kernel_variant], _lib.current_stream())
-        _lib.check(rc, "ntm_gru_forward")
+        fn, err = _lib.gru_forward_fn(self.kernel_variant, self.hidden_size)
+        rc = fn(ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0), ptr(o.weight),
+                ptr(o.bias), self.hidden_size, ptr(x2d), ptr(y2d), B, T, max(x2d.stride(0), T), max(y2d.stride(0), T), ptr(h),
+                _lib.VARIANTS[self.kernel_variant], _lib.current_stream())
+        _lib.check(rc, "ntm_gru_forward", err)
         self.hidden = h
         if self.skip:
             y2d += x2d
@@ -456,17 +458,47 @@ def spec_sums(output, target, skip=0, n_fft=1024, hop=None, win_length=None, log
     return out.sum(dim=1), n_frames * (int(n_fft) // 2 + 1)
 
 
+_MEL_CACHE = {}
+
+
+@torch.no_grad()
+def mel_sums(output, target, skip=0, n_fft=2048, hop=None, n_mels=160, sampling_rate=44100, log_floor=SPEC_LOG_FLOOR):
+    """Per-stream sums of the two mel entries of code/evaluation.py:86-92 (ntm_mel_sums): (B,4) fp64 =
+    sum |mel_y - mel_t| | sum |log10 max(mel_y,f) - log10 max(mel_t,f)| | sum mel_t | sum mel_y, and the cells per
+    stream (frames x mel bands).  The mel basis (`librosa.filters.mel(sr, n_fft, n_mels)`, restated in
+    utilities.mel_filterbank_sparse: parity unpinned) is built once per (sr, n_fft, n_mels, device) and kept."""
+    from .utilities import mel_filterbank_sparse
+    hop = int(n_fft) // 4 if hop is None else int(hop)
+    y = _as_bt(output, "mel_sums")
+    t = _as_bt(target, "mel_sums")
+    B, T = y.shape
+    key = (int(sampling_rate), int(n_fft), int(n_mels), y.device)
+    if key not in _MEL_CACHE:
+        first, start, w = mel_filterbank_sparse(sampling_rate, n_fft, n_mels)
+        _MEL_CACHE[key] = tuple(torch.from_numpy(a).to(y.device) for a in (first, start, w))
+    first, start, w = _MEL_CACHE[key]
+    n_frames = 1 + (T - int(skip)) // hop
+    chunks = max(1, min(-(-2048 // max(B, 1)), n_frames // 32))
+    out = torch.empty(B, 4 * chunks, 4, device=y.device, dtype=torch.float64)
+    rc = _lib.lib().ntm_mel_sums(ptr(y), ptr(t), B, T, int(skip), int(n_fft), hop, int(n_fft), float(log_floor), chunks,
+                                 int(n_mels), ptr(first), ptr(start), ptr(w), ptr(out), _lib.current_stream())
+    _lib.check(rc, "ntm_mel_sums")
+    return out.sum(dim=1), n_frames * int(n_mels)
+
+
 class ValLossSupervised(torch.nn.Module):
     """`val_loss_supervised` of code/evaluation.py:18-100 (the validation metric bundle of the adversarial run) on
     the device, for what can be pinned here: `ms_spec_loss` / `ms_log_spec_loss` (sum over the six scales of the
     mean absolute difference of the power spectrograms / of their clamped log10; `TimeFreqConverter` is torchaudio's
-    Spectrogram(n_fft, hop = n_fft/4, power 2) = torch.stft, golden g13), `ESR`, `ESRDCPre`, `MSE`.  The two mel
-    entries need librosa's filter bank, which is not available to pin: they are not produced.
+    Spectrogram(n_fft, hop = n_fft/4, power 2) = torch.stft, golden g13), `mel_spec_loss` / `log_mel_spec_loss` (the
+    n_fft = 2048 power spectrogram projected on 160 mel bands, :86-92; librosa's filter bank restated, parity
+    unpinned), `ESR`, `ESRDCPre`, `MSE` -- the same seven keys as the reference's dict.
     forward(output, target) with (B, T) or (B, 1, T) tensors -> dict of python floats."""
 
-    def __init__(self, spec_scales=SPEC_SCALES, log_eps=SPEC_LOG_FLOOR):
+    def __init__(self, spec_scales=SPEC_SCALES, log_eps=SPEC_LOG_FLOOR, n_mel_channels=160, sampling_rate=44100):
         super().__init__()
         self.spec_scales, self.log_eps = tuple(spec_scales), log_eps
+        self.n_mel_channels, self.sampling_rate = n_mel_channels, sampling_rate
 
     @torch.no_grad()
     def forward(self, output, target):
@@ -478,6 +510,9 @@ class ValLossSupervised(torch.nn.Module):
             tot = s.sum(dim=0) / (cells * s.shape[0])
             losses["ms_spec_loss"] += float(tot[0])
             losses["ms_log_spec_loss"] += float(tot[1])
+        m, cells = mel_sums(output, target, 0, 2048, None, self.n_mel_channels, self.sampling_rate, self.log_eps)
+        mt = m.sum(dim=0) / (cells * m.shape[0])
+        losses["mel_spec_loss"], losses["log_mel_spec_loss"] = float(mt[0]), float(mt[1])
         n = output.numel()
         e = esr_sums(output, target).sum(dim=0)
         losses["ESR"] = float((e[0] / n) / (e[1] / n + ESR_EPS))

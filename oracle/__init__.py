@@ -254,6 +254,69 @@ def spec_sums(y, t, skip=0, n_fft=1024, hop=None, win_length=None, log_floor=SPE
     return out, n_frames * (n_fft // 2 + 1)
 
 
+def mel_filterbank(sr=44100, n_fft=2048, n_mels=160, fmin=0.0, fmax=None):
+    """`librosa.filters.mel(sr=, n_fft=, n_mels=, fmin=, fmax=)` with its defaults (htk=False: the Slaney / Auditory
+    Toolbox mel scale; norm="slaney": every triangle scaled to unit area in Hz) -- the `mel_basis` of the reference's
+    TimeFreqConverter (code/utilities/utilities.py:639-646).  librosa is NOT installed in the build container and
+    the reference vendors no copy: this restates the published algorithm -- PARITY UNPINNED; tests check it against
+    the one value librosa's own docstring prints (0.016 = mel(sr=22050, n_fft=2048)[0, 1]) and the unit-area property.
+      mel(f)  = f / (200/3)                              for f < 1000 Hz
+              = 15 + ln(f / 1000) / (ln(6.4) / 27)       above
+      n_mels + 2 band edges equally spaced in mel between fmin and fmax (= sr/2); filter m rises from edge m to edge
+      m+1 and falls to edge m+2 (piecewise linear in Hz, evaluated at the FFT bin centres k sr / n_fft), then is
+      multiplied by 2 / (edge[m+2] - edge[m]).   -> float32 [n_mels, 1 + n_fft/2]"""
+    fmax = sr / 2.0 if fmax is None else fmax
+    f_sp, min_log_hz = 200.0 / 3.0, 1000.0
+    min_log_mel, logstep = min_log_hz / f_sp, np.log(6.4) / 27.0
+
+    def hz_to_mel(f):
+        f = np.asarray(f, np.float64)
+        return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-300) / min_log_hz) / logstep, f / f_sp)
+
+    def mel_to_hz(m):
+        m = np.asarray(m, np.float64)
+        return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+    fftfreqs = np.linspace(0.0, sr / 2.0, 1 + n_fft // 2)
+    mel_f = mel_to_hz(np.linspace(hz_to_mel(fmin), hz_to_mel(fmax), n_mels + 2))
+    fdiff = np.diff(mel_f)
+    ramps = mel_f[:, None] - fftfreqs[None, :]
+    w = np.zeros((n_mels, 1 + n_fft // 2))
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        w[i] = np.maximum(0.0, np.minimum(lower, upper))
+    w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]
+    return w.astype(np.float32)
+
+
+def mel_sums(y, t, skip=0, n_fft=2048, hop=None, n_mels=160, sr=44100, log_floor=SPEC_LOG_FLOOR):
+    """Per-stream sums of the two mel entries of val_loss_supervised.forward (code/evaluation.py:86-92): the power
+    spectrogram of `TimeFreqConverter(n_fft=2048, hop 512)` projected by `mel_basis` (matmul, :666), then
+    |mel_y - mel_t| and |log10 max(mel_y, 1e-5) - log10 max(mel_t, 1e-5)|.  Returns [B,4] float64: the two sums,
+    sum mel_t, sum mel_y, and the number of (mel band, frame) cells per stream."""
+    hop = n_fft // 4 if hop is None else hop
+    basis = mel_filterbank(sr, n_fft, n_mels).astype(np.float64)
+    y = np.asarray(y, np.float64)[:, skip:]
+    t = np.asarray(t, np.float64)[:, skip:]
+    B, L = y.shape
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)
+    n_frames = 1 + L // hop
+    idx = np.arange(n_frames)[:, None] * hop + np.arange(n_fft)[None, :]
+
+    def mel(x):
+        xp = np.pad(x, ((0, 0), (n_fft // 2, n_fft // 2)), mode="reflect")
+        X = np.fft.rfft(xp[:, idx] * win, axis=-1)
+        return (X.real ** 2 + X.imag ** 2) @ basis.T                          # [1, frames, mels]
+
+    out = np.empty((B, 4))
+    for b in range(B):
+        my, mt = mel(y[b:b + 1]), mel(t[b:b + 1])
+        out[b] = [np.abs(my - mt).sum(),
+                  np.abs(np.log10(np.maximum(my, log_floor)) - np.log10(np.maximum(mt, log_floor))).sum(), mt.sum(), my.sum()]
+    return out, n_frames * n_mels
+
+
 def ms_spec_losses(y, t, scales=SPEC_SCALES):
     """`ms_spec_loss` and `ms_log_spec_loss` of val_loss_supervised.forward (code/evaluation.py:75-84) over the
     whole batch: SUM over the scales of the mean absolute difference of the power spectrograms / of their
@@ -277,7 +340,9 @@ def _lin_interp(xk, yk, xn):
 def demodulate(output, x_idx_pulse, y_idx_pulse):
     """DelayAnalyzer.demodulate, code/utilities/utilities.py:408-465 (fp64): undo the time-varying delay of a
     (C, N) recording from its input / output pulse indices.  Pinned by golden g11 (the reference's own output)."""
-    output = np.asarray(output, np.float64)
+    output = np.asarray(output)                 # dtype kept: with float32 knot values (what code/dataset.py:397 passes)
+    if output.dtype not in (np.float32, np.float64):     # scipy forms y_hi - y_lo in float32, then a float64 slope
+        output = output.astype(np.float64)
     x_idx, y_idx = np.asarray(x_idx_pulse).reshape(-1), np.asarray(y_idx_pulse).reshape(-1)
     period = int(np.mean(np.diff(x_idx)))                                   # :436
     y_hat_idx = y_idx[0] + np.arange(len(y_idx)) * period                   # :437-438  (Eq. 57)

@@ -365,3 +365,37 @@ def test_g15_feeder_demodulated_items_equal_reference(ntm, tmp_path):
             assert np.abs(meta["delay_trajectory"].numpy() - g[f"c_{i}_traj"]).max() < 1e-8
             checked += 1
     assert checked == 3
+
+
+# ----------------------------------------------------------------------------- sharded CLI, fewer segments than ranks
+def test_cli_two_ranks_one_segment_does_not_hang(tmp_path):
+    """tools/test_model.py over 2 ranks (gloo, sharing this box's GPU) on a dataset with ONE segment: rank 1's shard is
+    empty.  Every rank must issue the same collectives whatever its shard holds (round 1 decided the MultiSTFT key per
+    rank: the empty rank would have issued 2 all-reduces against 3 and RCCL would have blocked).  Both ranks finish and
+    rank 0 reports the single segment's losses, equal to a one-process run."""
+    import socket
+    from scipy.io import wavfile
+    d = tmp_path / "One" / "Test"
+    d.mkdir(parents=True)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-0.4, 0.4, 6000).astype(np.float32)
+    wavfile.write(str(d / "input_1_.wav"), 44100, x)
+    wavfile.write(str(d / "target_1_.wav"), 44100, (0.5 * x).astype(np.float32))
+    args = [sys.executable, os.path.join(ROOT, "tools", "test_model.py"), "--DATASET_DIR", str(tmp_path / "One"), "--WEIGHTS", W_G,
+            "--COMPUTE_LOSS"]
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    one = subprocess.run(args, env=base, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(base, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   NTM_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen(args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    stats = lambda text: [ln for ln in text.splitlines() if ":" in ln and ln.split(":")[0].strip() in ("Segments", "ESR", "DCPreESR", "MultiSTFT")]  # noqa: E731
+    assert stats(outs[0][0]) == stats(one.stdout) and len(stats(one.stdout)) == 4 and "Segments:   1" in one.stdout
+    assert "Stats" not in outs[1][0]

@@ -12,8 +12,8 @@ import ntm_amd
 from helpers import GOLDEN, ROOT, state_dict_np
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "ntm.h")).read()
+def header_symbols(name="ntm.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(ntm_[a-z0-9_]+)\s*\(", text)))
 
@@ -26,6 +26,14 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"libntm.so does not export {s}"
     assert set(ntm_amd._lib._SIGNATURES) == set(syms)       # the ctypes table covers the whole header
+    assert not any(s.startswith("ntm_debug") or s.startswith("ntm_lab") for s in syms)
+    # the laboratory library (older / experimental kernels, diagnostic builds) has its own header and is separate
+    lab_syms = header_symbols("ntm_lab.h")
+    lab = ctypes.CDLL(ntm_amd._lib.LAB_PATH)
+    for s in lab_syms:
+        assert hasattr(lab, s), f"libntm_lab.so does not export {s}"
+        assert not hasattr(lib, s), f"the product library exports the laboratory symbol {s}"
+    assert set(ntm_amd._lib._LAB_SIGNATURES) == set(lab_syms)
     assert ntm_amd._lib.lib().ntm_abi_version() == 2 == ntm_amd._lib.ABI_VERSION
 
 

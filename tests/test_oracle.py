@@ -237,3 +237,23 @@ def test_oracle_under_address_and_ub_sanitizers():
                        timeout=600)
     assert r.returncode == 0 and "ASAN_DRIVER_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
     assert "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+
+
+def test_mel_filterbank_restatement():
+    """librosa is absent (parity unpinned): the Slaney filter bank is checked against the one value librosa's own
+    docstring prints for mel(sr=22050, n_fft=2048) -- 0.016 at [0, 1] --, the unit-area normalisation, and the
+    product's row-compressed form against the oracle's dense one."""
+    from ntm_amd.utilities import mel_filterbank_sparse
+    w = oracle.mel_filterbank(22050, 2048, 128)
+    assert w.shape == (128, 1025) and w.dtype == np.float32 and w[0, 0] == 0.0 and abs(w[0, 1] - 0.016) < 5e-4
+    assert np.all(w >= 0) and np.all(w[:, -1] == 0)
+    W = oracle.mel_filterbank(44100, 2048, 160)
+    area = W.astype(np.float64).sum(1) * 44100 / 2048            # unit area in Hz, up to the bin discretisation
+    assert np.all(np.abs(area - 1) < 0.12) and np.all(np.abs(area[100:] - 1) < 5e-3)   # narrow low bands: 2-3 bins each
+    peaks = W.argmax(1)
+    assert np.all(np.diff(peaks) >= 0) and np.count_nonzero(W) == np.count_nonzero(W > 0)
+    first, start, ww = mel_filterbank_sparse(44100, 2048, 160)
+    D = np.zeros_like(W)
+    for m in range(160):
+        D[m, first[m]:first[m] + start[m + 1] - start[m]] = ww[start[m]:start[m + 1]]
+    assert np.array_equal(D, W)                                    # two independent restatements agree bit for bit

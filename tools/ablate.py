@@ -12,6 +12,7 @@ x = torch.rand(B, T, device="cuda") - 0.5
 y = torch.empty_like(x)
 g, o = m.GRU, m.output
 L = ntm_amd._lib.lib()
+LAB = ntm_amd._lib.lab()          # stamps / ablations: diagnostic builds in libntm_lab.so
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
 NAMES = {0: "full kernel", 1: "no gates", 2: "no LDS exchange", 4: "no head", 8: "own-quarter MFMAs only (12)", 16: "no barrier",
          32: "no housekeeping", 3: "no gates, no LDS", 7: "no gates/LDS/head", 18: "no LDS, no barrier", 39: "no gates/LDS/head/hk",
@@ -25,7 +26,7 @@ def run(mask):
             rc = L.ntm_gru_forward_ex(ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0),
                                       ptr(o.weight), ptr(o.bias), 64, ptr(x), ptr(y), B, T, T, T, ptr(h), 3, None)
         else:
-            rc = L.ntm_debug_gru_ablate(ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0),
+            rc = LAB.ntm_debug_gru_ablate(ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0),
                                         ptr(o.weight), ptr(o.bias), ptr(x), ptr(y), B, T, ptr(h), mask, None)
         assert rc == 0, L.ntm_last_error()
         ev[1].record(); torch.cuda.synchronize()

@@ -13,11 +13,12 @@ y = torch.empty_like(x); h = torch.zeros(B, 64, device="cuda")
 st = torch.zeros((B + 15) // 16, 4, 6, dtype=torch.int64, device="cuda")
 g, o = m.GRU, m.output
 L = ntm_amd._lib.lib()
+LAB = ntm_amd._lib.lab()          # stamps / ablations: diagnostic builds in libntm_lab.so
 NAMES = {1: ["lds_read", "phaseA", "phaseB", "tail", "lds_write", "barrier"],
          3: ["mfma1-3(+bookkeeping)", "wait_own_wr", "barrier", "rd+45mfma", "hk+cinit+gates", "wr+head"]}
 for variant in (3, 1):
     for _ in range(2):
-        rc = L.ntm_debug_gru_stamps(ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0),
+        rc = LAB.ntm_debug_gru_stamps(ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0),
                                     ptr(o.weight), ptr(o.bias), ptr(x), ptr(y), B, T, ptr(h), ptr(st), variant, None)
         assert rc == 0, L.ntm_last_error()
         torch.cuda.synchronize()
