@@ -247,6 +247,138 @@ __global__ __launch_bounds__(256, 2) void tcn_block_mfma2_kernel(const float *in
     }
 }
 
+// ---- 32 -> 32 channel block for LARGE dilations: phase-GROUP tiles with a sliding window -------------------------
+// With dil = 1000 and T = 65 536 a phase holds 66 outputs: in polyphase tiles of 16 that is 5 tiles = 80 slots (17.5 %
+// wasted), every staged row is a separate 128-byte line dil rows away from the next, and the fused output conv stores y
+// with the polyphase stride (4-byte stores dil samples apart): 81.7 ms against 58.4 ms for the small dilations.
+// Here a tile is 16 ADJACENT phases at ONE time index: outputs n = 16 g + j + m dil, j = 0..15 (group g, time index m).
+// Tap k reads the rows 16 g + j + (m - 12 + k) dil: the 16 rows of "row block" (g, m - 12 + k), 2 KB contiguous in
+// memory.  A wave pair walks m = 0, 1, 2, ... for its group and keeps the last 13 row blocks in an LDS ring of 16
+// slots: ONE new 2 KB block per tile (a single 16-byte load per lane), no padding along time, and the fused
+// output conv stores 16 consecutive samples (64 bytes).  Same MFMA order per output as the polyphase kernel
+// (bit-identical results).  Two tiles (m, m + 1) per iteration and barrier.  Wasted slots: only the phases 16 g + j >=
+// dil of the last group (8 of 1008 for dil = 1000).
+constexpr int PG_SLOTS = 16;                 // ring of row blocks per pair (13 live + 2 being filled, power of two)
+constexpr int PG_BLK_F = 16 * TRS;           // floats per row block
+constexpr int PG_SMEM_FLOATS = 2 * PG_SLOTS * PG_BLK_F;     // two pairs: 73 728 B -> two workgroups per CU
+
+template <bool FUSE_OUT>
+__global__ __launch_bounds__(256, 2) void tcn_block_pg_kernel(const float *in, float *out, const float *W,
+                                                              const float *bias, const float *alpha, const float *R,
+                                                              int dil, int64_t T, int groups, const float *ow,
+                                                              const float *obias, float *yout)
+{
+    extern __shared__ __attribute__((aligned(16))) float tsm[];
+    __shared__ float ypp[2][2][2][16];        // FUSE_OUT: [iteration parity][pair][tile][sample] partial of wave mt = 1
+    const int tid = threadIdx.x, l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mt = w & 1, ng = w >> 1;
+    const int q = l >> 4, j = l & 15;
+    const int64_t b = blockIdx.x;
+    const int g = 2 * blockIdx.y + ng;                   // this pair's phase group (may be past the end: idles)
+    const bool gvalid = g < groups;
+    const float *ib = in + b * T * TC;
+    float *ob = out + b * T * TC;
+    const int mtot = (int)((T + dil - 1) / dil);         // time indices
+    const int niter = (mtot + 1) / 2;
+
+    float Aw[TK][8], Ar[8];
+#pragma unroll
+    for (int k = 0; k < TK; ++k)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) Aw[k][s] = W[((8 * q + s) * TK + k) * TC + 16 * mt + j];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) Ar[s] = R[(8 * q + s) * TC + 16 * mt + j];
+    f32x4 bi, al, owv = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { bi[v] = bias[16 * mt + 4 * q + v]; al[v] = alpha[16 * mt + 4 * q + v]; }
+    if constexpr (FUSE_OUT) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) owv[v] = ow[16 * mt + 4 * q + v];
+    }
+    float ypart[2] = {0.0f, 0.0f};
+    int64_t yn[2] = {T, T};
+    float *yb = FUSE_OUT ? yout + b * T : nullptr;
+    const float ob0 = FUSE_OUT ? obias[0] : 0.0f;
+    auto finish_y = [&](int parity) {                  // after the barrier: wave mt = 0 adds the other half and stores
+        if constexpr (FUSE_OUT) {
+            if (mt == 0 && q == 0) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    if (yn[nt] < T) yb[yn[nt]] = (ypart[nt] + ypp[parity][ng][nt][j]) + ob0;
+            }
+        }
+    };
+
+    // staging: a row block = 16 rows x 8 pieces of 16 B = 128 pieces = one per lane of the pair
+    const int e = mt * 64 + l, st_r = e >> 3, st_c8 = e & 7;
+    float *ring = tsm + ng * (PG_SLOTS * PG_BLK_F);
+    auto block_load = [&](int mb) -> f32x4 {             // row block (g, mb): rows 16 g + st_r + mb dil
+        const int64_t n = (int64_t)16 * g + st_r + (int64_t)mb * dil;
+        const bool ok = gvalid && mb >= 0 && n < T && 16 * g + st_r < dil + 16;   // (rows of aliased phases are real rows too)
+        const float *ptr = ok ? ib + n * TC + 4 * st_c8 : tcn_zeros + 4 * st_c8;
+        return *(const f32x4 *)ptr;
+    };
+    auto block_store = [&](int mb, f32x4 v) { *(f32x4 *)&ring[(mb & (PG_SLOTS - 1)) * PG_BLK_F + st_r * TRS + 4 * st_c8] = v; };
+    const int rd_base = j * TRS + 8 * q;
+
+    if (niter <= 0) return;
+    // prologue: blocks -12 .. -1 are zeros, blocks 0 and 1 come from memory
+    for (int mb = -12; mb < 0; ++mb) block_store(mb, (f32x4){0.0f, 0.0f, 0.0f, 0.0f});
+    block_store(0, block_load(0));
+    block_store(1, block_load(1));
+    __syncthreads();
+    for (int it = 0; it < niter; ++it) {
+        const int m0 = 2 * it;
+        const f32x4 nb0 = block_load(m0 + 2), nb1 = block_load(m0 + 3);     // the next iteration's new blocks
+        f32x4 acc[2], res[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) { acc[nt] = bi; res[nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
+#pragma unroll
+        for (int k = 0; k < TK; ++k) {
+            f32x4 lo[2], hi[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const float *tb = ring + ((m0 + nt - (TK - 1) + k) & (PG_SLOTS - 1)) * PG_BLK_F + rd_base;
+                lo[nt] = *(const f32x4 *)tb;
+                hi[nt] = *(const f32x4 *)(tb + 4);
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const float bv = s < 4 ? lo[nt][s] : hi[nt][s - 4];
+                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[k][s], bv, acc[nt], 0, 0, 0);
+                    if (k == TK - 1) res[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[s], bv, res[nt], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int p = 16 * g + j;                                        // phase of this lane's output column
+            const int64_t n = (gvalid && p < dil && m0 + nt < mtot) ? (int64_t)p + (int64_t)(m0 + nt) * dil : T;
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float u = acc[nt][c];
+                v[c] = (u >= 0.0f ? u : al[c] * u) + res[nt][c];
+            }
+            if constexpr (FUSE_OUT) {
+                float pp = (owv[0] * v[0] + owv[1] * v[1]) + (owv[2] * v[2] + owv[3] * v[3]);
+                pp += __shfl_xor(pp, 16, 64);
+                pp += __shfl_xor(pp, 32, 64);
+                if (mt == 1) { if (q == 0) ypp[it & 1][ng][nt][j] = pp; }
+                else { ypart[nt] = pp; yn[nt] = n; }
+            } else {
+                if (n < T) *(f32x4 *)(ob + n * TC + 16 * mt + 4 * q) = v;
+            }
+        }
+        block_store(m0 + 2, nb0);          // slots of blocks m0 - 14, m0 - 13: no tile of this iteration reads them
+        block_store(m0 + 3, nb1);
+        __syncthreads();
+        finish_y(it & 1);
+    }
+}
+
 // ---- 1x1 output conv: [B][T][32] -> y [B][T] --------------------------------------------------------
 __global__ __launch_bounds__(256) void tcn_out_kernel(const float *in, float *y, const float *ow, const float *ob,
                                                       int64_t T)
@@ -287,6 +419,27 @@ hipError_t launch_tcn(const float *params, int L, int C, int K, const int *dil, 
                                out, W, bias, alpha, R, T);
         else if (cin == 1) hipLaunchKernelGGL(tcn_first_kernel, gridf, dim3(256), 0, stream, in, out, W, bias, alpha, R, dil[l], T);
         else {
+            if (dil[l] >= 512) {
+                // large dilation: phase-group tiles with a sliding window (two groups per workgroup)
+                const int groups = (dil[l] + 15) / 16;
+                const dim3 gridg((unsigned)B, (unsigned)((groups + 1) / 2));
+                const size_t smem = PG_SMEM_FLOATS * sizeof(float);
+                if (l == L - 1) {
+                    auto k = tcn_block_pg_kernel<true>;
+                    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                    if (e != hipSuccess) return e;
+                    hipLaunchKernelGGL(k, gridg, dim3(256), smem, stream, in, out, W, bias, alpha, R, dil[l], T, groups, p, p + C, y);
+                    return hipGetLastError();
+                }
+                auto k = tcn_block_pg_kernel<false>;
+                hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                if (e != hipSuccess) return e;
+                hipLaunchKernelGGL(k, gridg, dim3(256), smem, stream, in, out, W, bias, alpha, R, dil[l], T, groups, nullptr,
+                                   nullptr, nullptr);
+                in = out;
+                cin = C;
+                continue;
+            }
             // polyphase tiles: M = ceil(T / dil) outputs per phase, tpp = ceil(M / 16) tiles per phase
             const int64_t M = (T + dil[l] - 1) / dil[l];
             const int tpp = (int)((M + 15) / 16);
