@@ -237,11 +237,21 @@ hipError_t launch_esr(const float *y, const float *t, int64_t B, int64_t T, int6
 
 // ---------------------------------------------------------------------------------------
 // K3b: DC-pre-emphasised ESR sums: both signals through H(z) = (1 - z^-1)/(1 - R z^-1) (zero state at
-// `skip`), then sum f(t-y)^2 and sum f(t)^2 per stream.  The recursion v[n] = R v[n-1] + u[n] is linear, so a
-// 256-thread block scans 4096 samples at a time: every thread runs its 16 samples from zero state, the
-// (R^16, end value) pairs are combined by a shuffle scan, and the incoming carry is added as R^(k+1) c.
+// `skip`), then sum f(t-y)^2 and sum f(t)^2 per stream.  The recursion v[n] = R v[n-1] + u[n] is linear.
+// One 256-thread block per stream; each of its four waves owns a CONTIGUOUS quarter of [skip, T) and streams through
+// it in chunks of 1024 samples WITHOUT any workgroup barrier (round 1 shared every chunk between the four waves:
+// two barriers per 4096 samples, 0.94 ms at 4096 x 65 536):
+//   * a chunk is fetched with coalesced loads and handed to the lanes through the wave's own LDS rows (lane l gets
+//     samples 16 l .. 16 l + 15; rows of 17 floats keep the reads conflict-free);
+//   * every lane runs its 16 samples from zero state, a shuffle scan of the (R^16, end value) pairs gives each lane
+//     the state entering it, the chunk's last state is carried to the next chunk in a register;
+//   * quarters 1..3 do not know the state c entering them, so a wave accumulates for its quarter (started from zero
+//     state)  S2 = sum v^2,  S1 = sum R^(k+1) v_k  and its end state E; with c the true sums are
+//     S2 + 2 c S1 + c^2 C2  (C2 = sum R^(2(k+1)), a geometric series) and the state leaving is R^len c + E: one thread
+//     chains the four quarters at the end.  fp64 accumulators.
 // ---------------------------------------------------------------------------------------
-constexpr int DCL = 16;   // samples per thread per chunk
+constexpr int DCL = 16;   // samples per lane per chunk
+constexpr int DCW = 64 * DCL;   // samples per wave and chunk
 
 __global__ __launch_bounds__(256) void esr_dcpre_kernel(const float *y, const float *t, int64_t T, int64_t skip, float R,
                                                         double *out)
@@ -253,31 +263,49 @@ __global__ __launch_bounds__(256) void esr_dcpre_kernel(const float *y, const fl
     rp[0] = 1.0f;
 #pragma unroll
     for (int k = 1; k <= DCL; ++k) rp[k] = rp[k - 1] * R;
-    __shared__ float wA[4], wBe[4], wBt[4], carry[2];
-    // the chunk is fetched with coalesced loads (lane-contiguous) and handed to the threads through LDS: a thread's
-    // 16 consecutive samples sit in a row of 17 floats (the pad keeps the row reads conflict-free).  Reading them
-    // straight from global memory (64-byte stride across lanes) cost 1.7 ms at 4096 x 65 536 instead of 0.6.
-    __shared__ float s_e[256 * (DCL + 1)], s_t[256 * (DCL + 1)];
-    if (tid == 0) { carry[0] = 0.0f; carry[1] = 0.0f; }
-    double se = 0.0, st = 0.0;
-    for (int64_t c0 = skip; c0 < T; c0 += 256 * DCL) {
-        __syncthreads();
-        const float cin_e = carry[0], cin_t = carry[1];
+    __shared__ float s_e[4][64 * (DCL + 1)], s_t[4][64 * (DCL + 1)];
+    __shared__ double q_sum[4][6];           // per quarter: S2e, S1e, Ee, S2t, S1t, Et
+    float *se_ = s_e[wv], *st_ = s_t[wv];
+
+    // this wave's quarter: whole chunks, the last quarter takes the remainder
+    const int64_t n_all = T - skip;
+    const int64_t chunks = (n_all + DCW - 1) / DCW, cq = (chunks + 3) / 4;
+    const int64_t q0 = skip + (int64_t)wv * cq * DCW;
+    const int64_t q1 = (skip + (int64_t)(wv + 1) * cq * DCW < T) ? skip + (int64_t)(wv + 1) * cq * DCW : T;
+
+    double S2e = 0.0, S1e = 0.0, S2t = 0.0, S1t = 0.0;
+    float ce = 0.0f, ct = 0.0f;              // state entering the chunk (the quarter starts from zero state)
+    const float r_chunk = powf(R, (float)DCW);
+    float wbase = powf(R, (float)(lane * DCL + 1));      // R^(k+1) of this lane's first sample of the chunk, k within the quarter
+    for (int64_t c0 = q0; c0 < q1; c0 += DCW) {
+        // all 32 loads of the chunk are issued before the first one is consumed (clamped addresses instead of
+        // per-load branches: with a branch and an LDS store behind every load the compiler waited for each load in
+        // turn -- 16 dependent HBM round trips per chunk, which is what held round 1's kernel at 0.94 ms)
+        float tvv[DCL], yvv[DCL];
+        const int64_t last = q1 - 1;
 #pragma unroll
         for (int i = 0; i < DCL; ++i) {
-            const int idx = i * 256 + tid;
-            const int64_t n = c0 + idx;
-            float tv = 0.0f, yv = 0.0f;
-            if (n < T) { tv = tb[n]; yv = yb[n]; }
-            s_t[(idx >> 4) * (DCL + 1) + (idx & 15)] = tv;
-            s_e[(idx >> 4) * (DCL + 1) + (idx & 15)] = tv - yv;
+            const int64_t n = c0 + i * 64 + lane;
+            const int64_t nc = n < q1 ? n : last;
+            tvv[i] = tb[nc];
+            yvv[i] = yb[nc];
         }
-        __syncthreads();
-        const int64_t n0 = c0 + (int64_t)tid * DCL;
+#pragma unroll
+        for (int i = 0; i < DCL; ++i) {
+            const int idx = i * 64 + lane;
+            const bool in = c0 + idx < q1;
+            const float tv = in ? tvv[i] : 0.0f, yv = in ? yvv[i] : 0.0f;
+            st_[(idx >> 4) * (DCL + 1) + (idx & 15)] = tv;
+            se_[(idx >> 4) * (DCL + 1) + (idx & 15)] = tv - yv;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int64_t n0 = c0 + (int64_t)lane * DCL;
         float ue[DCL], ut[DCL];
-        float pe = 0.0f, pt = 0.0f;
+        float pe = 0.0f, pt = 0.0f;          // the sample before this lane's run (input of the FIR part)
         if (n0 > skip && n0 - 1 < T) {
-            if (tid > 0) { pt = s_t[(tid - 1) * (DCL + 1) + DCL - 1]; pe = s_e[(tid - 1) * (DCL + 1) + DCL - 1]; }
+            if (lane > 0) { pt = st_[(lane - 1) * (DCL + 1) + DCL - 1]; pe = se_[(lane - 1) * (DCL + 1) + DCL - 1]; }
             else { pt = tb[n0 - 1]; pe = pt - yb[n0 - 1]; }
         }
         float fe = 0.0f, ft = 0.0f;
@@ -285,7 +313,7 @@ __global__ __launch_bounds__(256) void esr_dcpre_kernel(const float *y, const fl
         for (int k = 0; k < DCL; ++k) {
             const int64_t n = n0 + k;
             float tv = 0.0f, ev = 0.0f;
-            if (n < T) { tv = s_t[tid * (DCL + 1) + k]; ev = s_e[tid * (DCL + 1) + k]; } else { tv = pt; ev = pe; }   // past the end: u = 0
+            if (n < q1) { tv = st_[lane * (DCL + 1) + k]; ev = se_[lane * (DCL + 1) + k]; } else { tv = pt; ev = pe; }   // past the end: u = 0
             fe = (ev - pe) + R * fe;
             ft = (tv - pt) + R * ft;
             pe = ev; pt = tv;
@@ -298,38 +326,57 @@ __global__ __launch_bounds__(256) void esr_dcpre_kernel(const float *y, const fl
             const float Ap = __shfl_up(A, off), Bep = __shfl_up(Be, off), Btp = __shfl_up(Bt, off);
             if (lane >= off) { Be = __builtin_fmaf(A, Bep, Be); Bt = __builtin_fmaf(A, Btp, Bt); A *= Ap; }
         }
-        if (lane == 63) { wA[wv] = A; wBe[wv] = Be; wBt[wv] = Bt; }
-        // exclusive values for this lane
+        // state entering this lane: exclusive scan value applied to the chunk's incoming state
         float Ax = __shfl_up(A, 1), Bex = __shfl_up(Be, 1), Btx = __shfl_up(Bt, 1);
         if (lane == 0) { Ax = 1.0f; Bex = 0.0f; Btx = 0.0f; }
-        __syncthreads();
-        float ce = cin_e, ct = cin_t;        // carry entering this wave
-        for (int v = 0; v < wv; ++v) { ce = __builtin_fmaf(wA[v], ce, wBe[v]); ct = __builtin_fmaf(wA[v], ct, wBt[v]); }
-        const float le = __builtin_fmaf(Ax, ce, Bex), lt = __builtin_fmaf(Ax, ct, Btx);   // carry entering this lane
+        const float le = __builtin_fmaf(Ax, ce, Bex), lt = __builtin_fmaf(Ax, ct, Btx);
+        float wk = wbase;
 #pragma unroll
         for (int k = 0; k < DCL; ++k) {
-            if (n0 + k < T) {
+            if (n0 + k < q1) {
                 const float ve = __builtin_fmaf(rp[k + 1], le, ue[k]), vt = __builtin_fmaf(rp[k + 1], lt, ut[k]);
-                se += (double)ve * (double)ve;
-                st += (double)vt * (double)vt;
+                S2e += (double)ve * (double)ve;
+                S2t += (double)vt * (double)vt;
+                S1e += (double)(wk * ve);
+                S1t += (double)(wk * vt);
             }
+            wk *= R;
         }
-        if (tid == 255) {                    // carry leaving the chunk
-            carry[0] = __builtin_fmaf(rp[DCL], le, fe);
-            carry[1] = __builtin_fmaf(rp[DCL], lt, ft);
-        }
+        wbase *= r_chunk;
+        // state leaving the chunk = the inclusive value of lane 63 applied to the incoming state
+        const float Al = __shfl(A, 63), Bel = __shfl(Be, 63), Btl = __shfl(Bt, 63);
+        ce = __builtin_fmaf(Al, ce, Bel);
+        ct = __builtin_fmaf(Al, ct, Btl);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-        se += __shfl_down(se, off);
-        st += __shfl_down(st, off);
+        S2e += __shfl_down(S2e, off); S1e += __shfl_down(S1e, off);
+        S2t += __shfl_down(S2t, off); S1t += __shfl_down(S1t, off);
     }
-    __shared__ double part[2][4];
-    if (lane == 0) { part[0][wv] = se; part[1][wv] = st; }
+    if (lane == 0) {
+        q_sum[wv][0] = S2e; q_sum[wv][1] = S1e; q_sum[wv][2] = (double)ce;
+        q_sum[wv][3] = S2t; q_sum[wv][4] = S1t; q_sum[wv][5] = (double)ct;
+    }
     __syncthreads();
-    if (tid == 0) {
-        out[2 * b + 0] = (part[0][0] + part[0][1]) + (part[0][2] + part[0][3]);
-        out[2 * b + 1] = (part[1][0] + part[1][1]) + (part[1][2] + part[1][3]);
+    if (tid == 0) {                          // chain the quarters in order
+        const double Rd = (double)R, R2 = Rd * Rd;
+        double tot_e = 0.0, tot_t = 0.0, c_e = 0.0, c_t = 0.0;
+        for (int w = 0; w < 4; ++w) {
+            const int64_t a0 = skip + (int64_t)w * cq * DCW;
+            const int64_t a1 = (skip + (int64_t)(w + 1) * cq * DCW < T) ? skip + (int64_t)(w + 1) * cq * DCW : T;
+            const double len = a1 > a0 ? (double)(a1 - a0) : 0.0;
+            const double Aq = pow(Rd, len);
+            const double C2 = R2 < 1.0 ? R2 * (1.0 - Aq * Aq) / (1.0 - R2) : len;      // sum_{k<len} R^(2(k+1))
+            tot_e += q_sum[w][0] + 2.0 * c_e * q_sum[w][1] + c_e * c_e * C2;
+            tot_t += q_sum[w][3] + 2.0 * c_t * q_sum[w][4] + c_t * c_t * C2;
+            c_e = Aq * c_e + q_sum[w][2];
+            c_t = Aq * c_t + q_sum[w][5];
+        }
+        out[2 * b + 0] = tot_e;
+        out[2 * b + 1] = tot_t;
     }
 }
 
