@@ -208,6 +208,24 @@ int ntm_tape_hmag(const double *H, double *M, int64_t B, int64_t N, double *stat
                   const double *params5, void *stream);
 
 /*
+ * The resamplers of Tape.__call__ (code/tape.py:330-332,471-474,553-558: torchaudio.transforms.Resample -- sinc
+ * interpolation, Hann window, lowpass_filter_width 6, rolloff 0.99; torchaudio is un-vendored and absent here: the
+ * published algorithm, parity unpinned).  Polyphase FIR in fp64 with a caller-supplied kernel table (device,
+ * [up][2*width + down], built by ntm_amd.tape.sinc_resample_kernel):
+ *   y[b][i*up + p] = sum_k kernel[p][k] * xpad[b][i*down + k],  xpad[j] = x[j - width] (zero outside [0, N)),  i*up + p < M.
+ * x [B,N], y [B,M] fp64 device, contiguous.
+ */
+int ntm_resample_fir(const double *x, double *y, int64_t B, int64_t N, int64_t M, int up, int down, int width,
+                     const double *kernel, void *stream);
+
+/*
+ * The playback-loss filter of Tape.H_play (code/tape.py:565-574: torchaudio.functional.lfilter with a = [1, 0, ...],
+ * i.e. a FIR; clamp != 0 limits the output to [-1, 1] as lfilter's default does; zero initial state every call, as in the
+ * reference):  y[b][n] = sum_{k < taps, k <= n} h[k] x[b][n-k].   x, y [B,N] fp64 device; h [taps] fp64 device.
+ */
+int ntm_fir_f64(const double *x, double *y, int64_t B, int64_t N, const double *h, int taps, int clamp, void *stream);
+
+/*
  * Builder-defined causal dilated-Conv1d TCN (BASELINE.json config 4; the reference has no TCN:
  * code/micro_tcn is an empty submodule).  L causal blocks  out = PReLU(conv_dilated(in)) + conv1x1(in),
  * then a 1x1 conv to one channel.  params (device), block after block:

@@ -37,6 +37,8 @@ _SIGNATURES = {
     "ntm_demodulate": (_int, [_vp, _vp, _int, _i64, _vp, _int, _i64, _i64, _vp, _vp]),
     "ntm_tape_record_field": (_int, [_vp, _vp, _vp, _i64, _i64, ctypes.c_double, ctypes.c_double, _vp]),
     "ntm_tape_hmag": (_int, [_vp, _vp, _i64, _i64, _vp, ctypes.c_double, ctypes.POINTER(ctypes.c_double), _vp]),
+    "ntm_resample_fir": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp]),
+    "ntm_fir_f64": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _int, _vp]),
     "ntm_tcn_forward": (_int, [_vp, _int, _int, _int, ctypes.POINTER(_int), _vp, _vp, _i64, _i64, _vp, _vp]),
     "ntm_tcn_scratch_floats": (_i64, [_i64, _i64, _int]),
 }

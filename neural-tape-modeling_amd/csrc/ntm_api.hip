@@ -23,6 +23,9 @@ hipError_t launch_tape_record_field(const double *I, const double *bias, double 
                                     double gap, hipStream_t stream);
 hipError_t launch_tape_hmag(const double *H, double *M, int64_t B, int64_t N, double *state, double Ts, const double *par,
                             hipStream_t stream);
+hipError_t launch_resample_fir(const double *x, double *y, int64_t B, int64_t N, int64_t M, int up, int down, int width,
+                               const double *ker, hipStream_t stream);
+hipError_t launch_fir_f64(const double *x, double *y, int64_t B, int64_t N, const double *h, int taps, int clamp, hipStream_t stream);
 hipError_t launch_tcn(const float *params, int L, int C, int K, const int *dil, const float *x, float *y, int64_t B,
                       int64_t T, float *scratch, hipStream_t stream);
 }  // namespace ntm
@@ -243,6 +246,27 @@ int ntm_tape_hmag(const double *H, double *M, int64_t B, int64_t N, double *stat
     if (!H || !M || !state || !params5) return fail(NTM_EINVAL, "ntm_tape_hmag: null pointer");
     hipError_t e = ntm::launch_tape_hmag(H, M, B, N, state, Ts, params5, (hipStream_t)stream);
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_tape_hmag");
+}
+
+int ntm_resample_fir(const double *x, double *y, int64_t B, int64_t N, int64_t M, int up, int down, int width,
+                     const double *kernel, void *stream)
+{
+    if (B < 0 || N < 0 || M < 0 || up < 1 || down < 1 || width < 0) return fail(NTM_EINVAL, "ntm_resample_fir: bad size");
+    if (B > 65535) return fail(NTM_EINVAL, "ntm_resample_fir: at most 65535 streams per call");
+    if (B == 0 || M == 0) return NTM_OK;
+    if (!x || !y || !kernel || x == y) return fail(NTM_EINVAL, "ntm_resample_fir: null or aliased pointer");
+    hipError_t e = ntm::launch_resample_fir(x, y, B, N, M, up, down, width, kernel, (hipStream_t)stream);
+    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_resample_fir");
+}
+
+int ntm_fir_f64(const double *x, double *y, int64_t B, int64_t N, const double *h, int taps, int clamp, void *stream)
+{
+    if (B < 0 || N < 0 || taps < 1) return fail(NTM_EINVAL, "ntm_fir_f64: bad size");
+    if (B > 65535) return fail(NTM_EINVAL, "ntm_fir_f64: at most 65535 streams per call");
+    if (B == 0 || N == 0) return NTM_OK;
+    if (!x || !y || !h || x == y) return fail(NTM_EINVAL, "ntm_fir_f64: null or aliased pointer");
+    hipError_t e = ntm::launch_fir_f64(x, y, B, N, h, taps, clamp, (hipStream_t)stream);
+    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_fir_f64");
 }
 
 int64_t ntm_tcn_scratch_floats(int64_t B, int64_t T, int C)

@@ -132,6 +132,62 @@ hipError_t launch_tape_record_field(const double *I, const double *bias, double 
     return hipGetLastError();
 }
 
+// The two resamplers of Tape.__call__ (code/tape.py:330-332, 471-474, 553-558: torchaudio.transforms.Resample, sinc
+// interpolation with a Hann window -- the polyphase kernel table is built on the host, tape.py of this package): one thread
+// per output sample,
+//   y[i * up + p] = sum_k ker[p][k] * xpad[i * down + k],   xpad[j] = x[j - width]  (zero outside [0, N))
+// fp64, taps = 2 width + down (15 when oversampling by 16, 210 when coming back).  HBM / L2 bound streaming.
+__global__ __launch_bounds__(256) void resample_fir_kernel(const double *x, double *y, int64_t N, int64_t M, int up, int down,
+                                                           int width, const double *ker)
+{
+    const int64_t b = blockIdx.y;
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= M) return;
+    const int64_t i = o / up;
+    const int p = (int)(o - i * up);
+    const int taps = 2 * width + down;
+    const double *xb = x + b * N;
+    const double *kp = ker + (size_t)p * taps;
+    const int64_t j0 = i * down - width;
+    double acc = 0.0;
+    for (int k = 0; k < taps; ++k) {
+        const int64_t j = j0 + k;
+        if (j >= 0 && j < N) acc = __builtin_fma(kp[k], xb[j], acc);
+    }
+    y[b * M + o] = acc;
+}
+
+hipError_t launch_resample_fir(const double *x, double *y, int64_t B, int64_t N, int64_t M, int up, int down, int width,
+                               const double *ker, hipStream_t stream)
+{
+    if (B == 0 || M == 0) return hipSuccess;
+    hipLaunchKernelGGL(resample_fir_kernel, dim3((unsigned)((M + 255) / 256), (unsigned)B), dim3(256), 0, stream, x, y, N, M, up,
+                       down, width, ker);
+    return hipGetLastError();
+}
+
+// The playback-loss filter of Tape.H_play (code/tape.py:565-574: torchaudio.functional.lfilter with a = [1, 0, ...],
+// i.e. a FIR, output clamped to [-1, 1] like lfilter's default clamp=True; no state carried, as in the reference):
+//   y[n] = sum_{k < taps} h[k] x[n - k]
+__global__ __launch_bounds__(256) void fir_f64_kernel(const double *x, double *y, int64_t N, const double *h, int taps, int clamp)
+{
+    const int64_t b = blockIdx.y;
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const double *xb = x + b * N;
+    double acc = 0.0;
+    for (int k = 0; k < taps && k <= n; ++k) acc = __builtin_fma(h[k], xb[n - k], acc);
+    if (clamp) acc = acc < -1.0 ? -1.0 : (acc > 1.0 ? 1.0 : acc);
+    y[b * N + n] = acc;
+}
+
+hipError_t launch_fir_f64(const double *x, double *y, int64_t B, int64_t N, const double *h, int taps, int clamp, hipStream_t stream)
+{
+    if (B == 0 || N == 0) return hipSuccess;
+    hipLaunchKernelGGL(fir_f64_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0, stream, x, y, N, h, taps, clamp);
+    return hipGetLastError();
+}
+
 hipError_t launch_tape_hmag(const double *H, double *M, int64_t B, int64_t N, double *state, double Ts, const double *par,
                             hipStream_t stream)
 {

@@ -373,6 +373,41 @@ def tape_hmag(H, state=None, Ts=1.0 / (48000 * 16), params=TAPE_PARAMS):
     return M, state
 
 
+def sinc_resample(x, orig_freq, new_freq, lowpass_filter_width=6, rolloff=0.99):
+    """torchaudio.transforms.Resample(orig, new, dtype=float64) as code/tape.py:330-332,471-474,553-558 uses it (sinc
+    interpolation with a Hann window).  torchaudio is un-vendored AND absent from the build container: this restates
+    its published `_get_sinc_resample_kernel` / `_apply_sinc_resample_kernel` -- PARITY UNPINNED; tests check DC gain,
+    a band-limited sine and the round trip instead.  x [B,N] float64 -> [B, ceil(new N / orig)]."""
+    import math
+    x = np.asarray(x, np.float64)
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    B, N = x.shape
+    out_len = int(math.ceil(new * N / orig))
+    xp = np.pad(x, ((0, 0), (width, width + orig)))
+    frames = (xp.shape[1] - (2 * width + orig)) // orig + 1
+    y = np.zeros((B, frames * new))
+    for p in range(new):
+        for k in range(2 * width + orig):
+            t = (-p / new + (k - width) / orig) * base
+            t = min(max(t, -lowpass_filter_width), lowpass_filter_width)
+            wdw = math.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+            tt = t * math.pi
+            kv = (1.0 if tt == 0 else math.sin(tt) / tt) * wdw * (base / orig)
+            y[:, p::new] += kv * xp[:, k:k + (frames - 1) * orig + 1:orig]
+    return y[:, :out_len]
+
+
+def fir_clamp(x, h, clamp=True):
+    """torchaudio.functional.lfilter(x, a=[1,0,...], b=h) as code/tape.py:570-571 calls it: a FIR from zero state,
+    output clamped to [-1, 1] (lfilter's default).  PARITY UNPINNED (torchaudio absent)."""
+    x = np.asarray(x, np.float64)
+    y = np.stack([np.convolve(r, np.asarray(h, np.float64))[:x.shape[1]] for r in x])
+    return np.clip(y, -1.0, 1.0) if clamp else y
+
+
 def tcn_forward(params, L, C, K, dil, x, threads=1):
     x = _c(x)
     B, T = x.shape

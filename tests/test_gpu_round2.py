@@ -399,3 +399,45 @@ def test_cli_two_ranks_one_segment_does_not_hang(tmp_path):
     stats = lambda text: [ln for ln in text.splitlines() if ":" in ln and ln.split(":")[0].strip() in ("Segments", "ESR", "DCPreESR", "MultiSTFT")]  # noqa: E731
     assert stats(outs[0][0]) == stats(one.stdout) and len(stats(one.stdout)) == 4 and "Segments:   1" in one.stdout
     assert "Stats" not in outs[1][0]
+
+
+# ----------------------------------------------------------------------------- the rest of Tape.__call__
+def test_tape_resamplers_playback_filter_and_whole_chain(ntm):
+    """ntm_amd.Tape = the reference's Tape.__call__ (code/tape.py:389-464) on the device.  The sinc resamplers and the
+    lfilter playback loss follow torchaudio's published algorithms (torchaudio is absent: parity unpinned) and are
+    checked against the oracle's independent restatement; the magnetisation against the oracle pinned by golden g9;
+    the chain is stateful over two calls (bias phase, magnetisation, the downsampler's left context)."""
+    rng = np.random.default_rng(17)
+    B, N1, N2 = 3, 1500, 700
+    V = 0.5 * rng.standard_normal((B, N1 + N2))
+    tp = ntm.Tape(batch_size=B, startup_enable=False, playback_loss_enable=True)
+    # stage by stage
+    x = dev(V[:, :400])
+    up = tp.oversample(x)
+    assert up.shape == (B, 6400) and np.abs(up.cpu().numpy() - oracle.sinc_resample(V[:, :400], 48000, 768000)).max() < 1e-12
+    tp.M_OS, tp.M = up[:, :1600].clone(), torch.zeros(B, 100, dtype=torch.float64, device="cuda")
+    dn = tp.downsample(up[:, 1600:])
+    want = oracle.sinc_resample(up.cpu().numpy(), 768000, 48000)[:, 100:]
+    assert dn.shape == (B, 300) and np.abs(dn.cpu().numpy() - want).max() < 1e-12
+    m = dev(rng.standard_normal((B, 500)) * 2e5)
+    g_play = tp.PLAY_N * tp.PLAY_W * tp.PLAY_E * tp.TAPE_V * tp.PLAY_MU0 * tp.PLAY_G
+    assert np.abs(tp.H_play(m).cpu().numpy() - oracle.fir_clamp(g_play * m.cpu().numpy(), tp.b.cpu().numpy())).max() < 1e-12
+    # the whole chain, two stateful calls, against the oracle's composition of the same stages
+    tp = ntm.Tape(batch_size=B, startup_enable=False, playback_loss_enable=False)
+    ref = ntm.TapeMagnetization(batch_size=B)            # host-side bias waveform generator (pinned by golden g14)
+    outs, state, m_os_prev, m_prev = [], None, np.zeros((B, 0)), np.zeros((B, 0))
+    for sl in (slice(0, N1), slice(N1, N1 + N2)):
+        out = tp(dev(V[:, sl]))
+        I_os = oracle.sinc_resample(tp.signal_amplitude * V[:, sl], 48000, 768000)
+        H = (10.0 * (I_os + ref.bias_signal(I_os.shape[1])[None, :])) / 6e-6
+        M_os, state = oracle.tape_hmag(H, state, tp.Ts_OS)
+        M = oracle.sinc_resample(np.concatenate([m_os_prev, M_os], 1), 768000, 48000)[:, m_prev.shape[1]:]
+        m_os_prev, m_prev = M_os, M
+        want = tp.POST_GAIN * (g_play * M)
+        assert out.shape == (B, sl.stop - sl.start)
+        assert np.abs(out.cpu().numpy() - want).max() < 1e-6 * tp.POST_GAIN * g_play * tp.TAPE_Ms
+        outs.append(out)
+    # start-up (10 ms of silence through the chain, code/tape.py:376-386) and a batch smaller than batch_size
+    tp2 = ntm.Tape(batch_size=4)
+    y = tp2(dev(V[:2, :300]))
+    assert y.shape == (2, 300) and torch.isfinite(y).all() and tp2.FLAG_STARTUP is False

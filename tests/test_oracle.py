@@ -257,3 +257,43 @@ def test_mel_filterbank_restatement():
     for m in range(160):
         D[m, first[m]:first[m] + start[m + 1] - start[m]] = ww[start[m]:start[m + 1]]
     assert np.array_equal(D, W)                                    # two independent restatements agree bit for bit
+
+
+def test_sinc_resampler_restatement_properties():
+    """torchaudio's Resample is un-vendored and absent (parity unpinned): the oracle's loop form and the product's
+    kernel table (two independent restatements of the published algorithm) must agree, and behave like the documented
+    resampler: unit DC gain, a band-limited sine preserved, x16 up then /16 down the identity away from the edges."""
+    from ntm_amd.tape import sinc_resample_kernel
+    for orig, new in ((48000, 768000), (768000, 48000), (44100, 48000)):
+        ker, width, o, n = sinc_resample_kernel(orig, new)
+        imp = np.zeros((1, 40 * o))
+        imp[0, 20 * o] = 1.0
+        y = oracle.sinc_resample(imp, orig, new)[0]
+        # impulse response of the polyphase bank: y[i n + p] = ker[p][20 o + width - i o]
+        want = np.zeros_like(y)
+        for i in range(len(y) // n):
+            k = 20 * o + width - i * o
+            if 0 <= k < ker.shape[1]:
+                want[i * n:(i + 1) * n] = ker[:, k][:len(want[i * n:(i + 1) * n])]
+        assert np.abs(y - want).max() < 1e-15
+    t = np.arange(3000) / 48000.0
+    x = np.stack([np.sin(2 * np.pi * 1000 * t), np.ones_like(t), np.sin(2 * np.pi * 7000 * t + 1.0)])
+    up = oracle.sinc_resample(x, 48000, 768000)
+    assert up.shape == (3, 48000) and np.abs(up[1, 400:-400] - 1).max() < 2e-3      # passband ripple of the 15-tap phases
+    n16 = np.arange(48000) / 768000.0
+    assert np.abs(up[0, 400:-400] - np.sin(2 * np.pi * 1000 * n16)[400:-400]).max() < 1e-3
+    back = oracle.sinc_resample(up, 768000, 48000)
+    assert back.shape == x.shape and np.abs(back[:, 100:-100] - x[:, 100:-100]).max() < 2e-3
+
+
+def test_g17_playback_fir_coefficients():
+    """Tape._compute_filter (code/tape.py:333-374) needs no torchaudio: the product's coefficients against the
+    reference's own (golden g17)."""
+    import types
+    from ntm_amd.tape import Tape
+    g = load("g17_tape_playback_fir.npz")
+    for fs, n_fir in ((48000, 128), (44100, 64)):
+        ns = types.SimpleNamespace(fs=fs, N_FIR=n_fir, TAPE_V=7.5 * 2.54e-2, TAPE_DELTA=35e-6, PLAY_D=20e-6, PLAY_G=6e-6)
+        b = Tape._compute_filter(ns)
+        assert b.dtype == np.float64 and np.array_equal(b, g[f"b_{fs}_{n_fir}"])
+    assert np.array_equal(oracle.fir_clamp(np.array([[0.5, 0.0, 3.0]]), [1.0, 0.5]), [[0.5, 0.25, 1.0]])
