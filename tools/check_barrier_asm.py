@@ -30,7 +30,7 @@ def main():
     kernels = re.findall(r"^(_ZN3ntm16gru_mfma2_kernel\w+):[^\n]*\n(.*?)\n\s*\.amdhsa_kernel", text, flags=re.S | re.M)
     checked = 0
     for name, body in kernels:
-        m = re.match(r"_ZN3ntm16gru_mfma2_kernelILb1ELb(\d)ELi(\d+)ELi(\d)ELi(\d+)EEE", name)
+        m = re.match(r"_ZN3ntm16gru_mfma2_kernelILb1ELb(\d)ELi(\d+)ELi(\d)ELi(\d+)E(?:Lb\dE)?EE", name)
         if not m or m.group(1) == "1" or m.group(2) != "0":
             continue                                      # STAMP / ablation builds are diagnostics (they use lgkmcnt(0))
         # the step loop: from its "Inner Loop Header" label to the last branch back to it, taken as a CYCLIC sequence
