@@ -286,8 +286,11 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     const int ps = w ^ 1;
 
     if constexpr (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
-    auto step = [&](const int64_t t, auto cur_c) {
+    // hk_c: tile housekeeping of this step, decided at COMPILE time in whole tiles (0 none, 1 the ph == 2 work,
+    // 2 the ph == 34 work) so that the step carries no phase tests; -1 = test ph at run time (ragged last tile)
+    auto step = [&](const int64_t t, auto cur_c, auto hk_c) {
         constexpr int cur = decltype(cur_c)::value;   // == t & 1: which exchange buffer holds h_{t-1}
+        constexpr int HK = decltype(hk_c)::value;
         const int ph = (int)(t & 63);
         const int64_t tile = t >> 6;
         float hB[16];
@@ -400,12 +403,14 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 
         // tile housekeeping, once per 64 steps each (y partials of the previous tile are complete and
         // visible once step 64i+65 has passed its barrier)
-        if constexpr (ABL & 32) {
-        } else if (ph == 2) {
-            if (t > 65) { flush_y_tile(next_flush); ++next_flush; }
-            if ((tile + 1) * TT < T) load_x_tile(tile + 1, xr);
-        } else if (ph == 34) {
-            if ((tile + 1) * TT < T) store_x_tile(tile + 1, xr);
+        if constexpr (!(ABL & 32)) {
+            if (HK == 1 || (HK < 0 && ph == 2)) {
+                // the x loads go out before the flush's stores (no VMEM drain between them)
+                if ((tile + 1) * TT < T) load_x_tile(tile + 1, xr);
+                if (t > 65) { flush_y_tile(next_flush); ++next_flush; }
+            } else if (HK == 2 || (HK < 0 && ph == 34)) {
+                if ((tile + 1) * TT < T) store_x_tile(tile + 1, xr);
+            }
         }
 
         // ---- the VALU block ------------------------------------------------------------------------
@@ -486,9 +491,25 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
             last_ = ts_[5];
         }
     };
-    for (int64_t t = 0; t < T; t += 2) {
-        step(t, std::integral_constant<int, 0>{});
-        if (t + 1 < T) step(t + 1, std::integral_constant<int, 1>{});
+    {
+        using C0 = std::integral_constant<int, 0>;
+        using C1 = std::integral_constant<int, 1>;
+        using H0 = std::integral_constant<int, 0>;
+        using HA = std::integral_constant<int, 1>;
+        using HB = std::integral_constant<int, 2>;
+        using HR = std::integral_constant<int, -1>;
+        const int64_t full = (T / TT) * TT;
+        for (int64_t t0 = 0; t0 < full; t0 += TT) {          // whole tiles: housekeeping at compile-time positions
+            step(t0, C0{}, H0{}); step(t0 + 1, C1{}, H0{});
+            step(t0 + 2, C0{}, HA{}); step(t0 + 3, C1{}, H0{});
+            for (int p = 4; p < 34; p += 2) { step(t0 + p, C0{}, H0{}); step(t0 + p + 1, C1{}, H0{}); }
+            step(t0 + 34, C0{}, HB{}); step(t0 + 35, C1{}, H0{});
+            for (int p = 36; p < TT; p += 2) { step(t0 + p, C0{}, H0{}); step(t0 + p + 1, C1{}, H0{}); }
+        }
+        for (int64_t t = full; t < T; t += 2) {               // ragged last tile: phase tests at run time
+            step(t, C0{}, HR{});
+            if (t + 1 < T) step(t + 1, C1{}, HR{});
+        }
     }
     if constexpr (STAMP) {
         if (a.dbg && l == 0)

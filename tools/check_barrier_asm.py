@@ -33,39 +33,62 @@ def main():
         m = re.match(r"_ZN3ntm16gru_mfma2_kernelILb1ELb(\d)ELi(\d+)ELi(\d)ELi(\d+)E(?:Lb\dE)?EE", name)
         if not m or m.group(1) == "1" or m.group(2) != "0":
             continue                                      # STAMP / ablation builds are diagnostics (they use lgkmcnt(0))
-        # the step loop: from its "Inner Loop Header" label to the last branch back to it, taken as a CYCLIC sequence
-        # (the h write that a barrier waits for is at the end of the previous trip through the body)
-        raw = body.splitlines()
-        lines = None
-        for h in [i for i, ln in enumerate(raw) if "Inner Loop Header" in ln]:     # the step loop is the one with barriers
-            tag = "Header=" + raw[h].split(":")[0].strip().lstrip(".L")            # blocks of the loop carry this in their comment
-            cand, inside = [], True
-            for ln in raw[h + 1:]:
-                if re.match(r"\s*(\.LBB\w+:|; %bb\.\d+:)", ln):                       # a basic-block boundary
-                    inside = tag in ln
-                    continue
-                if inside and ln.split(";")[0].strip():
-                    cand.append(ln.split(";")[0].strip())
-            if "s_barrier" in cand:
-                assert lines is None, f"{name}: two loops with barriers"
-                lines = cand
-        assert lines, f"{name}: step loop not found"
-        n = len(lines)
-        step_barriers = [i for i, ln in enumerate(lines) if ln == "s_barrier" and "lgkmcnt(1)" in lines[i - 1]]
-        assert len(step_barriers) == 2, f"{name}: expected the two step barriers of the 2x unrolled loop, found {len(step_barriers)}"
-        for b in step_barriers:
-            between, k = [], 2
-            while k <= n:
-                ln = lines[(b - k) % n]
-                if re.match(r"ds_write(2)?_b(128|64)\b", ln):
-                    break
-                if LGKM.match(ln):
-                    between.append(ln)
-                k += 1
-            assert k <= n, f"{name}: no h-exchange write ahead of a step barrier"
-            ok = len(between) == 1 and between[0].startswith("ds_write_b32")
-            assert ok, f"{name}: between the h write and the step barrier: {between} (expected exactly one ds_write_b32)"
+        # Instructions in layout order, labels and branches kept as block boundaries.  The step is inlined several times
+        # (compile-time housekeeping positions), inside loops and in straight-line runs, so the invariant is checked as
+        # two local properties that compose over every path from one step copy to the next:
+        #   TAIL  from an h-exchange write forward to the next step barrier or block boundary: exactly one lgkm op, the
+        #         y-partial ds_write_b32;
+        #   HEAD  from a step barrier backward to the previous h-exchange write (then TAIL applies), to a block boundary
+        #         or to an `s_waitcnt lgkmcnt(0)`: no lgkm op other than that one ds_write_b32, and none at all when a
+        #         boundary is reached first (a step head entered from elsewhere carries no LDS / SMEM traffic).
+        ins = []
+        for ln in body.splitlines():
+            if re.match(r"\s*\.LBB\w+:", ln):
+                ins.append("LABEL")
+                continue
+            t = ln.split(";")[0].strip()
+            if t:
+                ins.append(t)
+        is_hw = lambda t: re.match(r"ds_write(2)?_b(128|64)\b", t) is not None          # noqa: E731
+        is_edge = lambda t: t == "LABEL" or re.match(r"s_c?branch", t) is not None or t == "s_endpgm"   # noqa: E731
+        is_drain = lambda t: t.startswith("s_waitcnt") and "lgkmcnt(0)" in t             # noqa: E731
+        barriers = [i for i, t in enumerate(ins) if t == "s_barrier" and "lgkmcnt(1)" in ins[i - 1]]
+        assert len(barriers) >= 2, f"{name}: expected several step barriers, found {len(barriers)}"
+        for b in barriers:                                                               # HEAD
+            found, k = [], b - 2
+            while k >= 0 and not (is_hw(ins[k]) or is_edge(ins[k]) or is_drain(ins[k])):
+                if LGKM.match(ins[k]):
+                    found.append(ins[k])
+                k -= 1
+            if k >= 0 and is_hw(ins[k]):
+                ok = len(found) == 1 and found[0].startswith("ds_write_b32")
+            else:
+                ok = found == [] or (len(found) == 1 and found[0].startswith("ds_write_b32"))
+            assert ok, f"{name}: ahead of a step barrier: {found}"
             checked += 1
+        tails = 0
+        for w in [i for i, t in enumerate(ins) if is_hw(t)]:                             # TAIL
+            found, k, end = [], w + 1, None
+            while k < len(ins):
+                t = ins[k]
+                if t == "s_barrier" and "lgkmcnt(1)" in ins[k - 1]:
+                    end = "barrier"
+                    break
+                if is_drain(t):
+                    end = "drain"
+                    break
+                if is_edge(t):
+                    end = "edge"
+                    break
+                if LGKM.match(t) and not t.startswith("s_waitcnt"):
+                    found.append(t)
+                k += 1
+            if end == "drain":
+                continue                                  # prologue: followed by a full wait (__syncthreads)
+            assert len(found) == 1 and found[0].startswith("ds_write_b32"), \
+                f"{name}: behind an h-exchange write (up to {end}): {found} (expected exactly one ds_write_b32)"
+            tails += 1
+        assert tails >= 2, f"{name}: only {tails} step tails found"
     assert checked >= 4, f"only {checked} step barriers checked"
     print(f"check_barrier_asm: {checked} step barriers in {len(kernels)} instantiations: ok")
 
