@@ -165,7 +165,10 @@ __global__ __launch_bounds__(64) void gru_mfma4_kernel(GruArgs a)
     }
     float *const yp_lane = yp + blk * YP + j * YS;
 
-    for (int64_t t = 0; t < T; ++t) {
+    // hk_c as in gru_mfma2.hip: tile housekeeping at compile-time positions in whole tiles (no phase tests in the step);
+    // -1 = test the phase at run time (ragged last tile)
+    auto step = [&](const int64_t t, auto hk_c) {
+        constexpr int HK = decltype(hk_c)::value;
         const int ph = (int)(t & 63);
         const int64_t tile = t >> 6;
         f32x4 acc_r = {cr[0][0], cr[0][1], cr[1][0], cr[1][1]};
@@ -195,12 +198,13 @@ __global__ __launch_bounds__(64) void gru_mfma4_kernel(GruArgs a)
         asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z), "+v"(xn));
 
         // tile housekeeping, once per 64 steps each
-        if (NTM4_ABL & 8) {
-        } else if (ph == 2) {
-            if (t > 65) { flush_y_tile(next_flush); ++next_flush; }
-            if ((tile + 1) * TT < T) xr = load_x_tile(tile + 1);
-        } else if (ph == 34) {
-            if ((tile + 1) * TT < T) store_x_tile(tile + 1, xr);
+        if (!(NTM4_ABL & 8)) {
+            if (HK == 1 || (HK < 0 && ph == 2)) {
+                if ((tile + 1) * TT < T) xr = load_x_tile(tile + 1);
+                if (t > 65) { flush_y_tile(next_flush); ++next_flush; }
+            } else if (HK == 2 || (HK < 0 && ph == 34)) {
+                if ((tile + 1) * TT < T) store_x_tile(tile + 1, xr);
+            }
         }
 
         // ---- the VALU block ------------------------------------------------------------------------------------
@@ -252,6 +256,20 @@ __global__ __launch_bounds__(64) void gru_mfma4_kernel(GruArgs a)
             const f32x2 pp = __builtin_elementwise_fma(hn[1], wo[1], hn[0] * wo[0]);
             yp_lane[(tile & 1) * 16 * YP + ph] = pp[0] + pp[1];
         }
+    };
+    {
+        using H0 = std::integral_constant<int, 0>;
+        using HA = std::integral_constant<int, 1>;
+        using HB = std::integral_constant<int, 2>;
+        using HR = std::integral_constant<int, -1>;
+        const int64_t full = (T / TT) * TT;
+        for (int64_t t0 = 0; t0 < full; t0 += TT) {
+            step(t0, H0{}); step(t0 + 1, H0{}); step(t0 + 2, HA{});
+            for (int p = 3; p < 34; ++p) step(t0 + p, H0{});
+            step(t0 + 34, HB{});
+            for (int p = 35; p < TT; ++p) step(t0 + p, H0{});
+        }
+        for (int64_t t = full; t < T; ++t) step(t, HR{});
     }
 
     // ---- epilogue: remaining y tiles, final state ------------------------------------------------------------------
