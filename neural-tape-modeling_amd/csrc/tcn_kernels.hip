@@ -334,23 +334,33 @@ __global__ __launch_bounds__(256, 2) void tcn_block_pg_kernel(const float *in, f
         f32x4 acc[2], res[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) { acc[nt] = bi; res[nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
-#pragma unroll
-        for (int k = 0; k < TK; ++k) {
-            f32x4 lo[2], hi[2];
+        // B operands: the ds_read_b128 of tap k + 1 are issued BEFORE the MFMAs of tap k (register double buffer, the
+        // scheduler pinned by sched_barrier): left to itself hipcc puts each read right in front of its first MFMA and
+        // every tap waits out the LDS latency (~110 of its 512 matrix-pipe cycles: the 0.83 of the first version)
+        f32x4 lo[2][2], hi[2][2];
+        auto tap_read = [&](int k, int buf) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const float *tb = ring + ((m0 + nt - (TK - 1) + k) & (PG_SLOTS - 1)) * PG_BLK_F + rd_base;
-                lo[nt] = *(const f32x4 *)tb;
-                hi[nt] = *(const f32x4 *)(tb + 4);
+                lo[buf][nt] = *(const f32x4 *)tb;
+                hi[buf][nt] = *(const f32x4 *)(tb + 4);
             }
+        };
+        tap_read(0, 0);
+#pragma unroll
+        for (int k = 0; k < TK; ++k) {
+            const int cb = k & 1;
+            if (k + 1 < TK) tap_read(k + 1, cb ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < 8; ++s)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const float bv = s < 4 ? lo[nt][s] : hi[nt][s - 4];
+                    const float bv = s < 4 ? lo[cb][nt][s] : hi[cb][nt][s - 4];
                     acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[k][s], bv, acc[nt], 0, 0, 0);
                     if (k == TK - 1) res[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[s], bv, res[nt], 0, 0, 0);
                 }
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
