@@ -164,18 +164,29 @@ __global__ __launch_bounds__(256, 2) void tcn_block_mfma2_kernel(const float *in
         st_goff[c] = (int64_t)(r - (TK - 1)) * dil * TC + 4 * c8;    // floats, relative to the tile's first output
         st_lds[c] = (ng * 4 + nt) * TILE_F + r * TRS + 4 * c8;
     }
-    // first output sample of tile tau (>= T for tiles beyond the end) and whether the tile starts a phase
-    auto tile_n0 = [&](int tau, bool &first) -> int64_t {
-        if (tau >= tiles_end) { first = false; return T; }
-        const int p = tau / tpp, t = tau - p * tpp;
-        first = (t == 0);
-        return (int64_t)p + (int64_t)(16 * t) * dil;
+    // Tile tau = p * tpp + t (phase p, tile t of the phase).  The pair's four tiles advance by 8 per iteration; their
+    // (p, t) are carried as wave-uniform counters (one division per tile before the loop instead of eight per
+    // iteration: scalar instructions inside the MFMA stream are not free, see gru_mfma2.hip).
+    struct TilePos { int tau, p, t; };
+    auto pos_init = [&](int tau) { TilePos q; q.tau = tau; q.p = tau / tpp; q.t = tau - q.p * tpp; return q; };
+    auto pos_advance = [&](TilePos &q) {
+        q.tau += 8; q.t += 8;
+        while (q.t >= tpp) { q.t -= tpp; ++q.p; }
     };
+    // first output sample of the tile (>= T for tiles beyond the end) and whether the tile starts a phase
+    auto tile_n0 = [&](const TilePos &q, bool &first) -> int64_t {
+        if (q.tau >= tiles_end) { first = false; return T; }
+        first = (q.t == 0);
+        return (int64_t)q.p + (int64_t)(16 * q.t) * dil;
+    };
+    TilePos pc[4], ps[4];                    // tiles of the iteration being computed / being staged
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) pc[nt] = ps[nt] = pos_init(tile0 + 4 * ng + nt);
     f32x4 sreg[7];
-    auto stage_load = [&](int it) {
+    auto stage_load = [&]() {               // loads the windows of the tiles in `ps`
         int64_t n0[4]; bool fst[4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) n0[nt] = tile_n0(tile0 + 8 * it + 4 * ng + nt, fst[nt]);
+        for (int nt = 0; nt < 4; ++nt) n0[nt] = tile_n0(ps[nt], fst[nt]);
 #pragma unroll
         for (int c = 0; c < 7; ++c) {
             const int nt = st_nt[c];
@@ -194,12 +205,16 @@ __global__ __launch_bounds__(256, 2) void tcn_block_mfma2_kernel(const float *in
     const int rd_base = (ng * 4) * TILE_F + j * TRS + 8 * q;   // + nt*TILE_F + k*TRS (+4 for the upper 4 channels)
 
     if (niter <= 0) return;
-    stage_load(0);
+    stage_load();
     stage_store(0);
     __syncthreads();
     for (int it = 0; it < niter; ++it) {
         const int buf = it & 1;
-        if (it + 1 < niter) stage_load(it + 1);
+        if (it + 1 < niter) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) pos_advance(ps[nt]);
+            stage_load();
+        }
         const float *tb = tsm + buf * (TCN2_SMEM_FLOATS / 2) + rd_base;
         f32x4 acc[4], res[4];
 #pragma unroll
@@ -224,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void tcn_block_mfma2_kernel(const float *in
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             bool fst;
-            const int64_t n = tile_n0(tile0 + 8 * it + 4 * ng + nt, fst) + (int64_t)j * dil;
+            const int64_t n = tile_n0(pc[nt], fst) + (int64_t)j * dil;
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -242,6 +257,8 @@ __global__ __launch_bounds__(256, 2) void tcn_block_mfma2_kernel(const float *in
             }
         }
         if (it + 1 < niter) stage_store(buf ^ 1);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) pos_advance(pc[nt]);
         __syncthreads();
         finish_y(it & 1);
     }
