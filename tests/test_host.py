@@ -166,3 +166,27 @@ def test_step_barrier_wait_count_matches_the_disassembly():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_barrier_asm.py")], capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_recorded_bench_line_follows_the_contract():
+    """The last default `python bench.py` line recorded on the MI355X (profiles/) carries every field of the driver's
+    contract, the roofline of the dominant kernel and the CPU baseline; its numbers are self-consistent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*bench_default*.json")))
+    assert files, "no recorded default bench line under profiles/"
+    d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "samples/s" and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert d["dtype"] == "f32" and d["scaling"] in ("weak", "strong") and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] in ("GB/s", "TFLOP/s")
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    # whole-job throughput = segments x samples x steps / time;  kernel time <= step time
+    seg, T = d["config"]["segments_total"], d["config"]["samples_per_segment"]
+    assert abs(d["value"] - seg * T / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert r["kernel_ms"] <= d["ms_per_step"]
+    assert abs(r["achieved"] - 25088.0 * seg * T / d["n_gpus"] / (r["kernel_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
