@@ -503,6 +503,14 @@ def main():
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(weights.W_GRU)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        # CPU leg, outside the timed region: scattered streams of the LAST timed step's output against the C oracle over
+        # the whole sequence (the oracle is the checker here, never the thing measured)
+        import oracle
+        rows = sorted({r for r in (1, 15, 16, 17, B // 2 - 1, B // 2, B - 2, B - 1) if 0 <= r < B})
+        w_or = oracle.Weights.from_state_dict({k: v.numpy() for k, v in weights.load_state_dict(weights.W_GRU).items()})
+        yo, _ = oracle.gru_predict(w_or, x[rows, 0].cpu().numpy(), threads=out["cpu_baseline"]["cores"])
+        out["checks"]["streams_vs_oracle"] = {"rows": rows, "samples_each": T,
+                                              "max_abs": float(np.abs(y[rows, 0].cpu().numpy() - yo).max()), "tolerance": 1e-5}
     print(json.dumps(out))
 
 
