@@ -326,7 +326,8 @@ def main():
     props = torch.cuda.get_device_properties(local)
     mine = torch.tensor([rank, local, int(getattr(props, "pci_bus_id", -1)), int(getattr(props, "pci_device_id", -1))],
                         dtype=torch.int64, device=dev)
-    if world > 1:
+    grouped = torch.distributed.is_initialized()      # world > 1, or one rank with NTM_DIST_FORCE_INIT=1
+    if grouped:
         allr = [torch.empty_like(mine) for _ in range(world)]
         torch.distributed.all_gather(allr, mine)
     else:
@@ -444,7 +445,7 @@ def main():
         ev0.record(); cp.copy_(x); ev1.record(); torch.cuda.synchronize()
     hbm_copy_gbs = 2.0 * x.numel() * 4 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
     del cp
-    if world > 1:
+    if grouped:
         D.barrier()
         torch.distributed.destroy_process_group()
     if rank != 0:
@@ -485,8 +486,8 @@ def main():
                                f"predict (warm-start + persistent GRU kernel) + ESR sums on a side stream under the next step's launch + one all-reduce of the per-step loss scalars",
                    "segments_total": total_segments, "segments_rank0": B, "samples_per_segment": T, "kernel": a.variant,
                    "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
-        "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else "none (single process)",
-        "rccl_ranks": world if backend == "nccl" else 0, "ranks": world, "rank_devices": rank_devices,
+        "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if grouped else "none (single process)",
+        "rccl_ranks": world if (backend == "nccl" and grouped) else 0, "ranks": world, "rank_devices": rank_devices,
         "realtime_factor": total_samples / elapsed / FS,
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": peak_tflops, "unit": "TFLOP/s",
                      "frac": tflops / peak_tflops, "traffic": traffic, "traffic_source": traffic_source,

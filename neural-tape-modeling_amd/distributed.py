@@ -12,8 +12,9 @@ import torch.distributed as dist
 
 
 def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* if WORLD_SIZE > 1.
-    Returns (rank, world_size, local_rank)."""
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* if WORLD_SIZE > 1 (or, with
+    NTM_DIST_FORCE_INIT=1, also for a single rank: every collective of the N-rank path then really runs on the
+    backend -- how the RCCL calls are exercised on a one-GPU box).  Returns (rank, world_size, local_rank)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -23,7 +24,8 @@ def init_from_env(backend=None):
         backend = os.environ.get("NTM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend != "nccl" and torch.cuda.is_available() and torch.cuda.device_count() > 0:
         local %= torch.cuda.device_count()
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("NTM_DIST_FORCE_INIT") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -50,7 +52,7 @@ def reduce_loss_sums(per_segment_loss, err_sums=None, group=None):
     v[1] = per_segment_loss.numel()
     if err_sums is not None:
         v[2:4] = err_sums.double().sum(dim=0)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
     v = v.cpu()
     n = int(v[1].item())
@@ -75,7 +77,7 @@ def reduce_many(local_vectors, group=None):
     if not local_vectors:
         return []
     V = torch.stack(local_vectors)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(V, op=dist.ReduceOp.SUM, group=group)
     V = V.cpu()
     out = []
@@ -89,11 +91,11 @@ def reduce_many(local_vectors, group=None):
 def max_over_ranks(value, device):
     """MAX all-reduce of one python float (used for the benchmark's elapsed time)."""
     t = torch.tensor([value], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()

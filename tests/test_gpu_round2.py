@@ -338,6 +338,28 @@ def test_bench_spawns_its_own_ranks_on_one_gpu_over_gloo():
         assert abs(out["value"] - total * 4096 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
 
 
+def test_bench_one_rank_process_group_runs_the_rccl_calls():
+    """The collectives of the N-rank bench path on the REAL backend: with NTM_DIST_FORCE_INIT=1 a single rank still
+    builds the process group (backend nccl = RCCL), all-gathers the rank/device table, all-reduces the K x 4 fp64 loss
+    scalars and the elapsed-time MAX, passes the barriers and destroys the group -- everything an 8-GPU launch does
+    except moving bytes over xGMI.  Same line as a plain one-process run otherwise."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k != "NTM_DIST_BACKEND"}
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NTM_DIST_FORCE_INIT="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--batch", "512", "--samples", "4096", "--no-cpu-baseline", "--no-extra"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["backend"].startswith("rccl") and out["rccl_ranks"] == 1 and out["ranks"] == 1
+    assert out["rank_devices"][0]["rank"] == 0 and out["rank_devices"][0]["device"] == 0
+    assert out["checks"]["segments"] == 512 and out["checks"]["esr_vs_first_pass"] == 0.0
+    assert out["checks"]["every_timed_step_same_loss"] is True
+
+
 # ----------------------------------------------------------------------------- feeder, demodulated items (golden g15 c)
 def test_g15_feeder_demodulated_items_equal_reference(ntm, tmp_path):
     """VADataset(demodulate=True).__getitem__ (code/dataset.py:395-408: demodulate the 2-channel target with the
