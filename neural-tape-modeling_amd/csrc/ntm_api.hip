@@ -272,7 +272,7 @@ int ntm_fir_f64(const double *x, double *y, int64_t B, int64_t N, const double *
 int64_t ntm_tcn_scratch_floats(int64_t B, int64_t T, int C)
 {
     if (B <= 0 || T <= 0 || C <= 0) return 0;
-    return 2 * B * T * (int64_t)C;
+    return 2 * (B * T * (int64_t)C + 16 * (int64_t)C);      // two activation buffers, each padded by one 16-row block
 }
 
 int ntm_tcn_forward(const float *params, int L, int C, int K, const int *dil, const float *x, float *y, int64_t B,

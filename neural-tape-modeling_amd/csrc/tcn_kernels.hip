@@ -15,7 +15,9 @@
 
 namespace ntm {
 
-__device__ float tcn_zeros[32];   // zero page for taps that fall before the start of a stream
+__device__ float tcn_zeros[16 * 32];   // zero page (one row block) for rows before the start of a stream / of no tile
+
+constexpr int TCN_PAD_FLOATS = 16 * 32;   // behind each activation buffer: a row block may reach 15 rows past T (read, never used)
 
 constexpr int TC = 32;    // channels
 constexpr int TK = 13;    // kernel size
@@ -86,6 +88,48 @@ __global__ __launch_bounds__(256) void tcn_first_d1_kernel(const float *x, float
     }
 }
 
+// PReLU(u) + r without compare / select pairs: hi = max(u, 0), lo = u - hi (exact: one of the two is u, the other 0),
+// alpha lo + hi is then u for u >= 0 and alpha u (one rounding, like the product in the select form) for u < 0 -- the
+// same values as `u >= 0 ? u : alpha u`.  v_max_f32 through asm: the builtin adds a canonicalising v_max per element.
+__device__ __forceinline__ f32x4 prelu_plus(const f32x4 u, const f32x4 alpha, const f32x4 r)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x4 o;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const f32x2 uu = {u[2 * h], u[2 * h + 1]}, aa = {alpha[2 * h], alpha[2 * h + 1]}, rr = {r[2 * h], r[2 * h + 1]};
+        f32x2 hi;
+        asm("v_max_f32 %0, 0, %1" : "=v"(hi[0]) : "v"(uu[0]));
+        asm("v_max_f32 %0, 0, %1" : "=v"(hi[1]) : "v"(uu[1]));
+        f32x2 lo;                                                    // u - hi in ONE packed op (hipcc emits two v_sub_f32)
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(lo) : "v"(uu), "v"(hi));
+        const f32x2 t = __builtin_elementwise_fma(aa, lo, hi) + rr;
+        o[2 * h] = t[0]; o[2 * h + 1] = t[1];
+    }
+    return o;
+}
+
+// lane partial of the 1x1 output conv over the lane's 4 channels, on packed ops: (w0 v0 + w2 v2) + (w1 v1 + w3 v3)
+__device__ __forceinline__ float dot4(const f32x4 wv, const f32x4 v)
+{
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 t = __builtin_elementwise_fma((f32x2){wv[2], wv[3]}, (f32x2){v[2], v[3]}, (f32x2){wv[0], wv[1]} * (f32x2){v[0], v[1]});
+    return t[0] + t[1];
+}
+
+// p(l) + p(l ^ 16), then that + the same of lane l ^ 32: the sum over the wave's four 16-lane groups, in every lane.
+// v_permlane*_swap exchanges halves of TWO registers in place; with a copy of p as the second one the two results add
+// up to p(l) + p(l ^ 32) resp. p(l) + p(l ^ 16) (as in gru_mfma2.hip; asm because hipcc folds the builtin's two results
+// when both operands hold the same value; the wait states around the swap are inside the string).
+__device__ __forceinline__ float sum_lane_groups(float p)
+{
+    float t;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(p), "=&v"(t));
+    p += t;
+    asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(p), "=&v"(t));
+    return p + t;
+}
+
 // ---- 32 -> 32 channel block, polyphase tile order + LDS staging (the one launch_tcn uses) -------------
 // A tile is 16 outputs of ONE phase of the dilation: n = p + (m0 + j) dil, j = 0..15.  Its 13 taps read the
 // rows m0 + j + k - 12 of the same phase, so consecutive taps reuse the same 28 input rows: they are staged
@@ -107,7 +151,7 @@ constexpr int TCN2_SMEM_FLOATS = 2 * 2 * 4 * TILE_F;   // [buffer][pair][tile]  
 template <bool FUSE_OUT>
 __global__ __launch_bounds__(256, 2) void tcn_block_mfma2_kernel(const float *in, float *out, const float *W,
                                                                  const float *bias, const float *alpha,
-                                                                 const float *R, int dil, int64_t T, int tpp,
+                                                                 const float *R, int dil, int64_t T64, int tpp,
                                                                  int total_tiles, const float *ow, const float *obias,
                                                                  float *yout)
 {
@@ -118,8 +162,9 @@ __global__ __launch_bounds__(256, 2) void tcn_block_mfma2_kernel(const float *in
     const int mt = w & 1, ng = w >> 1;
     const int q = l >> 4, j = l & 15;
     const int64_t b = blockIdx.x;
-    const float *ib = in + b * T * TC;
-    float *ob = out + b * T * TC;
+    const int T = (int)T64;                   // launch_tcn: T < 2^31 - 2^25, dil <= 2^20 (32-bit sample arithmetic below)
+    const float *ib = in + b * T64 * TC;
+    float *ob = out + b * T64 * TC;
     const int tile0 = blockIdx.y * TPW;
     const int tiles_end = (tile0 + TPW < total_tiles) ? tile0 + TPW : total_tiles;
     const int niter = (tiles_end - tile0 + 7) / 8;
@@ -139,68 +184,81 @@ __global__ __launch_bounds__(256, 2) void tcn_block_mfma2_kernel(const float *in
         for (int v = 0; v < 4; ++v) owv[v] = ow[16 * mt + 4 * q + v];
     }
     float ypart[4] = {0.0f, 0.0f, 0.0f, 0.0f};      // FUSE_OUT, wave mt = 0: own half of the last iteration's outputs
-    int64_t yn[4] = {T, T, T, T};
-    float *yb = FUSE_OUT ? yout + b * T : nullptr;
+    int yn[4] = {T, T, T, T};
+    float *yb = FUSE_OUT ? yout + b * T64 : nullptr;
     const float ob0 = FUSE_OUT ? obias[0] : 0.0f;
     auto finish_y = [&](int parity) {              // after the barrier: wave mt = 0 adds the other half and stores
         if constexpr (FUSE_OUT) {
             if (mt == 0 && q == 0) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
-                    if (yn[nt] < T) yb[yn[nt]] = (ypart[nt] + ypp[parity][ng][nt][j]) + ob0;
+                    if (yn[nt] < T) *(float *)((char *)yb + 4u * (unsigned)yn[nt]) = (ypart[nt] + ypp[parity][ng][nt][j]) + ob0;
             }
         }
     };
 
-    // staging: the pair's 4 windows = 112 rows x 8 pieces of 16 B = 896 pieces over its 128 lanes (7 each)
-    int st_nt[7], st_roff[7], st_lds[7];
-    int64_t st_goff[7];
-#pragma unroll
-    for (int c = 0; c < 7; ++c) {
-        const int e = mt * 64 + l + 128 * c;
-        const int nt = e / 224, r = (e % 224) >> 3, c8 = e & 7;
-        st_nt[c] = nt;
-        st_roff[c] = r - (TK - 1);                                  // row relative to the tile's first output
-        st_goff[c] = (int64_t)(r - (TK - 1)) * dil * TC + 4 * c8;    // floats, relative to the tile's first output
-        st_lds[c] = (ng * 4 + nt) * TILE_F + r * TRS + 4 * c8;
-    }
-    // Tile tau = p * tpp + t (phase p, tile t of the phase).  The pair's four tiles advance by 8 per iteration; their
-    // (p, t) are carried as wave-uniform counters (one division per tile before the loop instead of eight per
-    // iteration: scalar instructions inside the MFMA stream are not free, see gru_mfma2.hip).
+    // Staging.  A tile's window = 12 history rows + 16 output rows, 8 pieces of 16 B each; the pair's 128 lanes take it
+    // in two rounds: H = the 96 history pieces (lanes 96..127 repeat piece 95), O = the 128 output-row pieces.  The
+    // tile is the same for every lane of a load, so everything that depends on the tile is SCALAR -- the window base
+    // (or the zero page: history of the first tile of a phase, tiles past the end), and the number of samples left
+    // up to T -- and the per-lane part is a constant 32-bit offset plus one compare/select for rows >= T: 3 vector
+    // instructions per tile and no branch.  (The first version spread the 896 pieces of four tiles over 7 loads per
+    // lane and selected tile, base and validity per lane: 84 vector instructions and a dozen branches per iteration,
+    // 5 % of the launch -- vector instructions of either wave on a SIMD take matrix-pipe cycles, see gru_mfma2.hip.)
+    const int e0 = mt * 64 + l;
+    const int pH = e0 < 96 ? e0 : 95;
+    const int rH = pH >> 3, cH = pH & 7, rO = e0 >> 3, cO = e0 & 7;
+    const unsigned offH = (unsigned)(rH * dil * TC + 4 * cH) * 4u;                   // bytes from the window's first row
+    const unsigned offO = (unsigned)(rO * dil * TC + 4 * cO) * 4u;
+    const int ldsH = ng * 4 * TILE_F + rH * TRS + 4 * cH, ldsO = ng * 4 * TILE_F + (TK - 1 + rO) * TRS + 4 * cO;   // + nt * TILE_F
+    const unsigned offS = (unsigned)(j * dil * TC + 16 * mt + 4 * q) * 4u;                                         // the lane's output row
+    const int jdS = j * dil;
+    const unsigned hist_bytes = (unsigned)(TK - 1) * (unsigned)dil * TC * 4u;
+
+    // Tile tau = p * tpp + t (phase p, tile t of the phase).  The pair's four tiles advance by 8 per iteration; (p, t)
+    // are carried as wave-uniform counters: t += 8 mod tpp with carry into p, as compare + selects (any tpp).
     struct TilePos { int tau, p, t; };
-    auto pos_init = [&](int tau) { TilePos q; q.tau = tau; q.p = tau / tpp; q.t = tau - q.p * tpp; return q; };
-    auto pos_advance = [&](TilePos &q) {
-        q.tau += 8; q.t += 8;
-        while (q.t >= tpp) { q.t -= tpp; ++q.p; }
+    const int adv_p = 8 / tpp, adv_t = 8 - adv_p * tpp;
+    auto pos_init = [&](int tau) { TilePos r; r.tau = tau; r.p = tau / tpp; r.t = tau - r.p * tpp; return r; };
+    auto pos_advance = [&](TilePos &r) {
+        r.tau += 8; r.t += adv_t; r.p += adv_p;
+        const bool wrap = r.t >= tpp;
+        r.t = wrap ? r.t - tpp : r.t;
+        r.p = wrap ? r.p + 1 : r.p;
     };
-    // first output sample of the tile (>= T for tiles beyond the end) and whether the tile starts a phase
-    auto tile_n0 = [&](const TilePos &q, bool &first) -> int64_t {
-        if (q.tau >= tiles_end) { first = false; return T; }
-        first = (q.t == 0);
-        return (int64_t)q.p + (int64_t)(16 * q.t) * dil;
+    // first output sample n0 of the tile and rem = samples from n0 to T (<= 0: none; always for tiles past the end)
+    auto tile_span = [&](const TilePos &r, int &n0, int &rem) {
+        n0 = r.p + 16 * r.t * dil;
+        rem = r.tau < tiles_end ? T - n0 : 0;
     };
     TilePos pc[4], ps[4];                    // tiles of the iteration being computed / being staged
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) pc[nt] = ps[nt] = pos_init(tile0 + 4 * ng + nt);
-    f32x4 sreg[7];
+    f32x4 sreg[8];
     auto stage_load = [&]() {               // loads the windows of the tiles in `ps`
-        int64_t n0[4]; bool fst[4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) n0[nt] = tile_n0(ps[nt], fst[nt]);
-#pragma unroll
-        for (int c = 0; c < 7; ++c) {
-            const int nt = st_nt[c];
-            const int64_t base = nt == 0 ? n0[0] : nt == 1 ? n0[1] : nt == 2 ? n0[2] : n0[3];
-            const bool f = nt == 0 ? fst[0] : nt == 1 ? fst[1] : nt == 2 ? fst[2] : fst[3];
-            const int64_t n = base + (int64_t)st_roff[c] * dil;
-            const bool ok = n < T && !(f && st_roff[c] < 0);
-            const float *ptr = ok ? ib + base * TC + st_goff[c] : tcn_zeros + (st_goff[c] & 31);
-            sreg[c] = *(const f32x4 *)ptr;
+        for (int nt = 0; nt < 4; ++nt) {
+            int n0, rem;
+            tile_span(ps[nt], n0, rem);
+            const bool some = rem > 0, hist = some && ps[nt].t != 0;
+            const char *bO = some ? (const char *)(ib + (int64_t)n0 * TC) : (const char *)tcn_zeros;
+            const char *bH = hist ? bO - hist_bytes : (const char *)tcn_zeros;
+            // scalar byte limits; a lane offset beyond them is clamped to an in-bounds 16-byte piece whose content nobody
+            // uses (rows >= T feed only outputs >= T) resp. to the zero page (offsets are multiples of 16)
+            const int remc = rem < (1 << 24) ? rem : (1 << 24);
+            const unsigned limO = some ? (unsigned)(remc - 1) * (TC * 4u) + (TC * 4u - 16u) : 0u;
+            const unsigned limH = hist ? 0xffffffffu : (TC * 4u - 16u);
+            sreg[2 * nt] = *(const f32x4 *)(bH + __builtin_elementwise_min(offH, limH));
+            sreg[2 * nt + 1] = *(const f32x4 *)(bO + __builtin_elementwise_min(offO, limO));
         }
     };
     auto stage_store = [&](int buf) {
+        float *dst = tsm + buf * (TCN2_SMEM_FLOATS / 2);
 #pragma unroll
-        for (int c = 0; c < 7; ++c) *(f32x4 *)&tsm[buf * (TCN2_SMEM_FLOATS / 2) + st_lds[c]] = sreg[c];
+        for (int nt = 0; nt < 4; ++nt) {
+            *(f32x4 *)&dst[ldsH + nt * TILE_F] = sreg[2 * nt];
+            *(f32x4 *)&dst[ldsO + nt * TILE_F] = sreg[2 * nt + 1];
+        }
     };
     const int rd_base = (ng * 4) * TILE_F + j * TRS + 8 * q;   // + nt*TILE_F + k*TRS (+4 for the upper 4 channels)
 
@@ -208,13 +266,17 @@ __global__ __launch_bounds__(256, 2) void tcn_block_mfma2_kernel(const float *in
     stage_load();
     stage_store(0);
     __syncthreads();
+    // every load of the prologue (weights, bias) is complete before the loop: otherwise hipcc parks a vmcnt wait for them
+    // at the loop head, which on every later iteration waits for the epilogue's stores instead (loads and stores
+    // share the counter on gfx9-class hardware)
+    __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0), other counters untouched
     for (int it = 0; it < niter; ++it) {
         const int buf = it & 1;
-        if (it + 1 < niter) {
+        // the next iteration's windows (past the last iteration: tiles >= tiles_end, i.e. the zero page)
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) pos_advance(ps[nt]);
-            stage_load();
-        }
+        for (int nt = 0; nt < 4; ++nt) pos_advance(ps[nt]);
+        stage_load();
+        __builtin_amdgcn_sched_barrier(0);      // the loads go out HERE, a whole iteration of MFMAs ahead of their use (hipcc sinks them to the epilogue otherwise)
         const float *tb = tsm + buf * (TCN2_SMEM_FLOATS / 2) + rd_base;
         f32x4 acc[4], res[4];
 #pragma unroll
@@ -236,27 +298,24 @@ __global__ __launch_bounds__(256, 2) void tcn_block_mfma2_kernel(const float *in
                     if (k == TK - 1) res[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[s], bv, res[nt], 0, 0, 0);
                 }
         }
+        // The staged windows go to LDS BEFORE the epilogue's global stores: the wait for the loads (issued a whole MFMA
+        // block ago) is then free.  Behind the stores it is a vmcnt(0) that also waits for the stores' acknowledgement,
+        // ~1500 cycles per iteration (stores and loads share the counter; the stores sit in a divergent branch, so hipcc
+        // cannot count them and waits for everything).
+        stage_store(buf ^ 1);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            bool fst;
-            const int64_t n = tile_n0(pc[nt], fst) + (int64_t)j * dil;
-            f32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float u = acc[nt][e];
-                v[e] = (u >= 0.0f ? u : al[e] * u) + res[nt][e];
-            }
+            int n0, rem;
+            tile_span(pc[nt], n0, rem);
+            const f32x4 v = prelu_plus(acc[nt], al, res[nt]);
             if constexpr (FUSE_OUT) {
-                float p = (owv[0] * v[0] + owv[1] * v[1]) + (owv[2] * v[2] + owv[3] * v[3]);
-                p += __shfl_xor(p, 16, 64);
-                p += __shfl_xor(p, 32, 64);
+                const float p = sum_lane_groups(dot4(owv, v));
                 if (mt == 1) { if (q == 0) ypp[it & 1][ng][nt][j] = p; }
-                else { ypart[nt] = p; yn[nt] = n; }
+                else { ypart[nt] = p; yn[nt] = jdS < rem ? n0 + jdS : T; }
             } else {
-                if (n < T) *(f32x4 *)(ob + n * TC + 16 * mt + 4 * q) = v;
+                if (jdS < rem) *(f32x4 *)((char *)(ob + (int64_t)n0 * TC) + offS) = v;
             }
         }
-        if (it + 1 < niter) stage_store(buf ^ 1);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) pos_advance(pc[nt]);
         __syncthreads();
@@ -279,10 +338,12 @@ constexpr int PG_SLOTS = 16;                 // ring of row blocks per pair (13 
 constexpr int PG_BLK_F = 16 * TRS;           // floats per row block
 constexpr int PG_SMEM_FLOATS = 2 * PG_SLOTS * PG_BLK_F;     // two pairs: 73 728 B -> two workgroups per CU
 
+template <int V> struct IntC { static constexpr int value = V; };
+
 template <bool FUSE_OUT>
 __global__ __launch_bounds__(256, 2) void tcn_block_pg_kernel(const float *in, float *out, const float *W,
                                                               const float *bias, const float *alpha, const float *R,
-                                                              int dil, int64_t T, int groups, const float *ow,
+                                                              int dil, int64_t T64, int groups, const float *ow,
                                                               const float *obias, float *yout)
 {
     extern __shared__ __attribute__((aligned(16))) float tsm[];
@@ -294,9 +355,10 @@ __global__ __launch_bounds__(256, 2) void tcn_block_pg_kernel(const float *in, f
     const int64_t b = blockIdx.x;
     const int g = 2 * blockIdx.y + ng;                   // this pair's phase group (may be past the end: idles)
     const bool gvalid = g < groups;
-    const float *ib = in + b * T * TC;
-    float *ob = out + b * T * TC;
-    const int mtot = (int)((T + dil - 1) / dil);         // time indices
+    const int T = (int)T64;                              // launch_tcn: T < 2^31, dil <= 2^20 (32-bit sample arithmetic)
+    const float *ib = in + b * T64 * TC;
+    float *ob = out + b * T64 * TC;
+    const int mtot = (int)((T64 + dil - 1) / dil);       // time indices
     const int niter = (mtot + 1) / 2;
 
     float Aw[TK][8], Ar[8];
@@ -314,95 +376,123 @@ __global__ __launch_bounds__(256, 2) void tcn_block_pg_kernel(const float *in, f
         for (int v = 0; v < 4; ++v) owv[v] = ow[16 * mt + 4 * q + v];
     }
     float ypart[2] = {0.0f, 0.0f};
-    int64_t yn[2] = {T, T};
-    float *yb = FUSE_OUT ? yout + b * T : nullptr;
+    int yn[2] = {T, T};
+    float *yb = FUSE_OUT ? yout + b * T64 : nullptr;
     const float ob0 = FUSE_OUT ? obias[0] : 0.0f;
-    auto finish_y = [&](int parity) {                  // after the barrier: wave mt = 0 adds the other half and stores
-        if constexpr (FUSE_OUT) {
-            if (mt == 0 && q == 0) {
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    if (yn[nt] < T) yb[yn[nt]] = (ypart[nt] + ypp[parity][ng][nt][j]) + ob0;
-            }
-        }
-    };
 
-    // staging: a row block = 16 rows x 8 pieces of 16 B = 128 pieces = one per lane of the pair
+    // staging: a row block = 16 rows x 8 pieces of 16 B = 128 pieces = one per lane of the pair, 2 KB contiguous.  The
+    // block is the same for every lane: a scalar base (the block, or the zero page when the group / the time index does
+    // not exist) plus a constant lane offset -- no vector arithmetic at all.  A block that straddles T is read whole:
+    // its rows >= T feed only outputs >= T, and they are in bounds because launch_tcn pads every activation buffer by
+    // one row block.
     const int e = mt * 64 + l, st_r = e >> 3, st_c8 = e & 7;
+    const unsigned voff = (unsigned)(st_r * TC + 4 * st_c8) * 4u;
     float *ring = tsm + ng * (PG_SLOTS * PG_BLK_F);
-    auto block_load = [&](int mb) -> f32x4 {             // row block (g, mb): rows 16 g + st_r + mb dil
-        const int64_t n = (int64_t)16 * g + st_r + (int64_t)mb * dil;
-        const bool ok = gvalid && mb >= 0 && n < T && 16 * g + st_r < dil + 16;   // (rows of aliased phases are real rows too)
-        const float *ptr = ok ? ib + n * TC + 4 * st_c8 : tcn_zeros + 4 * st_c8;
-        return *(const f32x4 *)ptr;
+    float *const st_lds = ring + st_r * TRS + 4 * st_c8;                       // + slot * PG_BLK_F
+    const float *const rd_lds = ring + j * TRS + 8 * q;                        // + slot * PG_BLK_F (+ 4: upper 4 channels)
+    const int g16 = 16 * g;
+    auto block_load = [&](int mb) -> f32x4 {             // mb >= 0.  (rows of aliased phases >= dil are real rows too)
+        const int n0 = g16 + mb * dil;                   // < T + dil + 16 g: no overflow
+        const char *base = (gvalid && n0 < T) ? (const char *)(ib + (int64_t)n0 * TC) : (const char *)tcn_zeros;
+        return *(const f32x4 *)(base + voff);
     };
-    auto block_store = [&](int mb, f32x4 v) { *(f32x4 *)&ring[(mb & (PG_SLOTS - 1)) * PG_BLK_F + st_r * TRS + 4 * st_c8] = v; };
-    const int rd_base = j * TRS + 8 * q;
+    // the lane's output sample inside a row block: row j if its phase 16 g + j exists, else "never valid"
+    const int jrow = (gvalid && g16 + j < dil) ? j : 0x40000000;
+    const unsigned offS = (unsigned)(j * TC + 16 * mt + 4 * q) * 4u;
 
     if (niter <= 0) return;
     // prologue: blocks -12 .. -1 are zeros, blocks 0 and 1 come from memory
-    for (int mb = -12; mb < 0; ++mb) block_store(mb, (f32x4){0.0f, 0.0f, 0.0f, 0.0f});
-    block_store(0, block_load(0));
-    block_store(1, block_load(1));
+#pragma unroll
+    for (int sl = PG_SLOTS - (TK - 1); sl < PG_SLOTS; ++sl) *(f32x4 *)(st_lds + sl * PG_BLK_F) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    *(f32x4 *)(st_lds + 0 * PG_BLK_F) = block_load(0);
+    *(f32x4 *)(st_lds + 1 * PG_BLK_F) = block_load(1);
     __syncthreads();
-    for (int it = 0; it < niter; ++it) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);      // vmcnt(0): no prologue load is pending at the loop head (see tcn_block_mfma2_kernel)
+
+    // One iteration = the tiles m0 = 2 it and m0 + 1.  The ring slot of row block mb is mb & 15, so the slots an iteration
+    // touches depend only on PH = it & 7: the loop is unrolled over the 8 phases and every LDS address is the lane's
+    // base register + an immediate (the rolled form needed a v_add per block -- 17 of the ~100 vector instructions
+    // per iteration, and a vector instruction of either wave on a SIMD costs ~8 matrix-pipe cycles).
+    auto iteration = [&](const int it, auto ph_c) {
+        constexpr int PH = decltype(ph_c)::value;
+        constexpr int S0 = 2 * PH;                        // slot of row block m0
         const int m0 = 2 * it;
         const f32x4 nb0 = block_load(m0 + 2), nb1 = block_load(m0 + 3);     // the next iteration's new blocks
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 acc[2], res[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) { acc[nt] = bi; res[nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
-        // B operands: the ds_read_b128 of tap k + 1 are issued BEFORE the MFMAs of tap k (register double buffer, the
-        // scheduler pinned by sched_barrier): left to itself hipcc puts each read right in front of its first MFMA and
-        // every tap waits out the LDS latency (~110 of its 512 matrix-pipe cycles: the 0.83 of the first version)
-        f32x4 lo[2][2], hi[2][2];
-        auto tap_read = [&](int k, int buf) {
+        // B operands.  Tap k of tile m0 + 1 reads the row block that tap k + 1 of tile m0 reads: the iteration walks
+        // the 14 blocks m0 - 12 .. m0 + 1 once (28 ds_read_b128 instead of 52) and feeds each to both tiles, taps in
+        // ascending order per output as before.  The reads of block s + 1 are issued BEFORE the MFMAs of block s
+        // (register double buffer, the scheduler pinned by sched_barrier): left to itself hipcc puts each read right in
+        // front of its first MFMA and every block waits out the LDS latency.
+        f32x4 lo[2], hi[2];
+#define PG_READ(s, buf)                                                                         \
+        {                                                                                       \
+            const int sl = (S0 - (TK - 1) + (s) + 2 * PG_SLOTS) & (PG_SLOTS - 1);               \
+            lo[buf] = *(const f32x4 *)(rd_lds + sl * PG_BLK_F);                                 \
+            hi[buf] = *(const f32x4 *)(rd_lds + sl * PG_BLK_F + 4);                             \
+        }
+        PG_READ(0, 0)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const float *tb = ring + ((m0 + nt - (TK - 1) + k) & (PG_SLOTS - 1)) * PG_BLK_F + rd_base;
-                lo[buf][nt] = *(const f32x4 *)tb;
-                hi[buf][nt] = *(const f32x4 *)(tb + 4);
-            }
-        };
-        tap_read(0, 0);
-#pragma unroll
-        for (int k = 0; k < TK; ++k) {
-            const int cb = k & 1;
-            if (k + 1 < TK) tap_read(k + 1, cb ^ 1);
+        for (int s = 0; s <= TK; ++s) {
+            const int cb = s & 1;
+            if (s + 1 <= TK) PG_READ(s + 1, cb ^ 1)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const float bv = s < 4 ? lo[cb][nt][s] : hi[cb][nt][s - 4];
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[k][s], bv, acc[nt], 0, 0, 0);
-                    if (k == TK - 1) res[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[s], bv, res[nt], 0, 0, 0);
-                }
+            for (int c = 0; c < 8; ++c) {
+                const float bv = c < 4 ? lo[cb][c] : hi[cb][c - 4];
+                if (s < TK) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[s < TK ? s : 0][c], bv, acc[0], 0, 0, 0);
+                if (s >= 1) acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Aw[s >= 1 ? s - 1 : 0][c], bv, acc[1], 0, 0, 0);
+                if (s == TK - 1) res[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[c], bv, res[0], 0, 0, 0);
+                if (s == TK) res[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Ar[c], bv, res[1], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
+#undef PG_READ
+        // new row blocks -> ring BEFORE the epilogue's global stores (see tcn_block_mfma2_kernel); their slots are
+        // those of blocks m0 - 14, m0 - 13, which no tile of this iteration reads
+        *(f32x4 *)(st_lds + ((S0 + 2) & (PG_SLOTS - 1)) * PG_BLK_F) = nb0;
+        *(f32x4 *)(st_lds + ((S0 + 3) & (PG_SLOTS - 1)) * PG_BLK_F) = nb1;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const int p = 16 * g + j;                                        // phase of this lane's output column
-            const int64_t n = (gvalid && p < dil && m0 + nt < mtot) ? (int64_t)p + (int64_t)(m0 + nt) * dil : T;
-            f32x4 v;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float u = acc[nt][c];
-                v[c] = (u >= 0.0f ? u : al[c] * u) + res[nt][c];
-            }
+            const int n0 = g16 + (m0 + nt) * dil;          // first sample of the tile's row block
+            const int rem = T - n0;                         // rows left up to T (<= 0: none)
+            const f32x4 v = prelu_plus(acc[nt], al, res[nt]);
             if constexpr (FUSE_OUT) {
-                float pp = (owv[0] * v[0] + owv[1] * v[1]) + (owv[2] * v[2] + owv[3] * v[3]);
-                pp += __shfl_xor(pp, 16, 64);
-                pp += __shfl_xor(pp, 32, 64);
-                if (mt == 1) { if (q == 0) ypp[it & 1][ng][nt][j] = pp; }
-                else { ypart[nt] = pp; yn[nt] = n; }
+                const float pp = sum_lane_groups(dot4(owv, v));
+                if (mt == 1) { if (q == 0) ypp[PH & 1][ng][nt][j] = pp; }
+                else { ypart[nt] = pp; yn[nt] = jrow < rem ? n0 + j : T; }
             } else {
-                if (n < T) *(f32x4 *)(ob + n * TC + 16 * mt + 4 * q) = v;
+                if (jrow < rem) *(f32x4 *)((char *)(ob + (int64_t)n0 * TC) + offS) = v;
             }
         }
-        block_store(m0 + 2, nb0);          // slots of blocks m0 - 14, m0 - 13: no tile of this iteration reads them
-        block_store(m0 + 3, nb1);
         __syncthreads();
-        finish_y(it & 1);
+        if constexpr (FUSE_OUT) {                          // wave mt = 0 adds the other half and stores
+            if (mt == 0 && q == 0) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    if (yn[nt] < T) *(float *)((char *)yb + 4u * (unsigned)yn[nt]) = (ypart[nt] + ypp[PH & 1][ng][nt][j]) + ob0;
+            }
+        }
+    };
+    for (int it = 0; it < niter; it += 8) {
+        iteration(it, IntC<0>{});
+        if (it + 1 >= niter) break;
+        iteration(it + 1, IntC<1>{});
+        if (it + 2 >= niter) break;
+        iteration(it + 2, IntC<2>{});
+        if (it + 3 >= niter) break;
+        iteration(it + 3, IntC<3>{});
+        if (it + 4 >= niter) break;
+        iteration(it + 4, IntC<4>{});
+        if (it + 5 >= niter) break;
+        iteration(it + 5, IntC<5>{});
+        if (it + 6 >= niter) break;
+        iteration(it + 6, IntC<6>{});
+        if (it + 7 >= niter) break;
+        iteration(it + 7, IntC<7>{});
     }
 }
 
@@ -429,7 +519,10 @@ hipError_t launch_tcn(const float *params, int L, int C, int K, const int *dil, 
 {
     if (B == 0 || T == 0) return hipSuccess;
     if (C != TC || K != TK) return hipErrorInvalidValue;
-    float *bufA = scratch, *bufB = scratch + (size_t)B * C * T;
+    if (T >= ((int64_t)1 << 31) - (1 << 25)) return hipErrorInvalidValue;   // 32-bit sample arithmetic in the block kernels
+    for (int l = 0; l < L; ++l)
+        if (dil[l] <= 0 || dil[l] > (1 << 20)) return hipErrorInvalidValue;
+    float *bufA = scratch, *bufB = scratch + (size_t)B * C * T + TCN_PAD_FLOATS;     // each followed by one row block of padding
     const float *p = params;
     const dim3 grid1((unsigned)B, (unsigned)((T + 255) / 256));
     const dim3 gridf((unsigned)B, (unsigned)((T + 31) / 32));

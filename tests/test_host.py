@@ -39,7 +39,7 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
 
 def test_cabi_pure_host_entry_points():
     L = ntm_amd._lib.lib()
-    assert L.ntm_tcn_scratch_floats(2, 100, 32) == 2 * 2 * 100 * 32
+    assert L.ntm_tcn_scratch_floats(2, 100, 32) == 2 * (2 * 100 * 32 + 16 * 32)      # two activation buffers + one row block of padding each
     # argument validation happens before anything touches a device
     assert L.ntm_gru_forward(None, None, None, None, None, None, 24, None, None, 1, 1, 1, 1, None, None) == -1
     assert b"8, 16, 32 and 64" in L.ntm_last_error()
