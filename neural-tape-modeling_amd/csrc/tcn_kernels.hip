@@ -48,43 +48,71 @@ __global__ __launch_bounds__(256) void tcn_first_kernel(const float *x, float *o
     *(f32x4 *)(out + (b * T + n) * TC + 4 * c4) = v;
 }
 
-// ---- first block, dilation 1 (the frozen spec): thread -> (8 consecutive samples, group of 4 output channels) --
-// The 8 samples share a window of 20 inputs (loaded once, 13 x 8 in the generic kernel) and the 13 weight
-// vectors stay in registers; the kernel then runs at the rate of its 34 GB of output.  Same operation order per
-// output as the generic kernel (bit-identical results).
+// ---- first block, dilation 1 (the frozen spec) ---------------------------------------------------------------
+// A workgroup walks FC chunks of 256 consecutive samples of one stream; thread -> (8 consecutive samples, group of 4
+// output channels): a wave writes 8 KiB contiguous per chunk.  The 8 samples share a window of 20 inputs; a chunk's
+// 256 samples + 12 of history go through LDS (double-buffered: one coalesced, branch-free load per thread -- index
+// clamped into the stream, zero selected outside -- issued a chunk ahead, one barrier per chunk), the window is five
+// ds_read_b128.  The 13 weight vectors are loaded once per workgroup and stay in registers.  (History: with the
+// window loaded per thread every load sat behind its own bounds branch, and every 256-sample workgroup re-loaded the
+// weights: 8.9 ms for the 34 GB of output; a pure store of that array takes 5.9 ms, tools/ubench/store_pattern.hip.)
+// Same operation order per output as the generic kernel (bit-identical results).
+constexpr int FC = 8;                          // chunks per workgroup
+
 __global__ __launch_bounds__(256) void tcn_first_d1_kernel(const float *x, float *out, const float *W, const float *bias,
                                                            const float *alpha, const float *R, int64_t T)
 {
-    constexpr int S = 8;
+    constexpr int S = 8, NB = 32 * S;         // samples per thread and chunk / per chunk
     const int64_t b = blockIdx.x;
-    const int c4 = threadIdx.x & 7;
-    const int64_t n0 = ((int64_t)blockIdx.y * 32 + (threadIdx.x >> 3)) * S;
-    if (n0 >= T) return;
+    const int c4 = threadIdx.x & 7, g = threadIdx.x >> 3;
+    const int64_t first = (int64_t)blockIdx.y * (FC * NB);
     const float *xb = x + b * T;
-    float xw[S + TK - 1];
-#pragma unroll
-    for (int i = 0; i < S + TK - 1; ++i) {
-        const int64_t src = n0 - (TK - 1) + i;
-        xw[i] = (src >= 0 && src < T) ? xb[src] : 0.0f;
-    }
+    __shared__ __attribute__((aligned(16))) float xs[2][NB + 16];
+    auto chunk_load = [&](int64_t base, int i) -> float {        // element i of the chunk's window [base - 12, base + 256)
+        const int64_t src = base - (TK - 1) + i;
+        const int64_t sc = src < 0 ? 0 : (src > T - 1 ? T - 1 : src);
+        const float v = xb[sc];
+        return sc == src ? v : 0.0f;
+    };
+    const int i1 = 256 + (threadIdx.x & 15);                     // second element (only NB + 12 - 256 = 12 are needed; 16 stored)
+    float va = chunk_load(first, threadIdx.x), vb = chunk_load(first, i1 < NB + TK - 1 ? i1 : NB + TK - 2);
     f32x4 wv[TK];
 #pragma unroll
     for (int k = 0; k < TK; ++k) wv[k] = *(const f32x4 *)(W + k * TC + 4 * c4);
     const f32x4 bi = *(const f32x4 *)(bias + 4 * c4), al = *(const f32x4 *)(alpha + 4 * c4), rv = *(const f32x4 *)(R + 4 * c4);
-    float *ob = out + (b * T + n0) * TC + 4 * c4;
+    for (int c = 0; c < FC; ++c) {
+        const int64_t base = first + (int64_t)c * NB;
+        if (base >= T) break;
+        float *xc = xs[c & 1];
+        xc[threadIdx.x] = va;
+        if (threadIdx.x < 16) xc[i1 < NB + TK - 1 ? i1 : NB + TK - 2] = vb;
+        __syncthreads();                       // (the buffer written two chunks ago was last read before the previous barrier)
+        if (c + 1 < FC && base + NB < T) {     // next chunk's window, in flight during this chunk's arithmetic
+            va = chunk_load(base + NB, threadIdx.x);
+            vb = chunk_load(base + NB, i1 < NB + TK - 1 ? i1 : NB + TK - 2);
+        }
+        const int64_t n0 = base + g * S;
+        float xw[S + TK - 1];
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-        if (n0 + s >= T) break;
-        f32x4 acc = bi;
+        for (int i = 0; i < (S + TK - 1) / 4; ++i) {
+            const f32x4 v = *(const f32x4 *)&xc[g * S + 4 * i];
 #pragma unroll
-        for (int k = 0; k < TK; ++k)
+            for (int e = 0; e < 4; ++e) xw[4 * i + e] = v[e];
+        }
+        float *ob = out + (b * T + n0) * TC + 4 * c4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(wv[k][e], xw[s + k], acc[e]);
-        const float x0 = xw[s + TK - 1];
-        f32x4 v;
+        for (int s = 0; s < S; ++s) {
+            f32x4 acc = bi;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(rv[e], x0, acc[e] >= 0.0f ? acc[e] : al[e] * acc[e]);
-        *(f32x4 *)(ob + (int64_t)s * TC) = v;
+            for (int k = 0; k < TK; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(wv[k][e], xw[s + k], acc[e]);
+            const float x0 = xw[s + TK - 1];
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(rv[e], x0, acc[e] >= 0.0f ? acc[e] : al[e] * acc[e]);
+            if (n0 + s < T) *(f32x4 *)(ob + (int64_t)s * TC) = v;
+        }
     }
 }
 
@@ -535,7 +563,7 @@ hipError_t launch_tcn(const float *params, int L, int C, int K, const int *dil, 
         const float *R = p;      p += (size_t)C * cin;
         float *out = (l & 1) ? bufB : bufA;
         if (cin == 1 && dil[l] == 1)
-            hipLaunchKernelGGL(tcn_first_d1_kernel, dim3((unsigned)B, (unsigned)((T + 255) / 256)), dim3(256), 0, stream, in,
+            hipLaunchKernelGGL(tcn_first_d1_kernel, dim3((unsigned)B, (unsigned)((T + FC * 256 - 1) / (FC * 256))), dim3(256), 0, stream, in,
                                out, W, bias, alpha, R, T);
         else if (cin == 1) hipLaunchKernelGGL(tcn_first_kernel, gridf, dim3(256), 0, stream, in, out, W, bias, alpha, R, dil[l], T);
         else {
