@@ -414,7 +414,10 @@ def test_harness_compute_loss_gru_and_diffdel(ntm):
 
 # ----------------------------------------------------------------------------- TCN (builder-defined)
 @pytest.mark.parametrize("B,T,dil", [(3, 700, (1, 3, 9, 27)), (2, 4000, (1, 10, 100, 1000)), (1, 1, (1, 10, 100, 1000)),
-                                     (2, 900, (2, 5, 1, 3)), (2, 300, (1,)), (3, 1030, (1, 7))])
+                                     (2, 900, (2, 5, 1, 3)), (2, 300, (1,)), (3, 1030, (1, 7)),
+                                     # dilations >= 512 take the phase-group kernel: as inner blocks (activation written), as
+                                     # the last one (output conv fused), with T not a multiple of anything
+                                     (2, 5000, (1, 1000, 600, 10)), (1, 40001, (1, 3000, 512)), (2, 2047, (1, 700))])
 def test_tcn_vs_oracle(ntm, B, T, dil):
     m = ntm.TCN(dilations=dil).to("cuda")
     rng = np.random.default_rng(B * 7 + T)
