@@ -230,7 +230,8 @@ int ntm_fir_f64(const double *x, double *y, int64_t B, int64_t N, const double *
  * code/micro_tcn is an empty submodule).  L causal blocks  out = PReLU(conv_dilated(in)) + conv1x1(in),
  * then a 1x1 conv to one channel.  params (device), block after block:
  *   W[C_in][K][C], b[C], alpha[C], R[C_in][C]   (C_in = 1 for block 0, C afterwards), then out_w[C], out_b[1].  x,y [B,T] contiguous; dil[L] host array; `scratch`
- * holds ntm_tcn_scratch_floats(B,T,C) floats.
+ * holds ntm_tcn_scratch_floats(B,T,C) floats (two activation buffers, each padded by one 16-row block: always ask this
+ * function).  Limits: T < 2^31 - 2^25, 1 <= dil[l] <= 2^20 (NTM_EINVAL otherwise).
  */
 int ntm_tcn_forward(const float *params, int L, int C, int K, const int *dil, const float *x,
                     float *y, int64_t B, int64_t T, float *scratch, void *stream);

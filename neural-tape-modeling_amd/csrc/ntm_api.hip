@@ -284,6 +284,9 @@ int ntm_tcn_forward(const float *params, int L, int C, int K, const int *dil, co
     if (!params || !dil || !x || !y || !scratch) return fail(NTM_EINVAL, "ntm_tcn_forward: null pointer");
     if ((reinterpret_cast<uintptr_t>(params) & 15) || (reinterpret_cast<uintptr_t>(scratch) & 15))
         return fail(NTM_EINVAL, "ntm_tcn_forward: params and scratch must be 16-byte aligned");
+    if (T >= ((int64_t)1 << 31) - (1 << 25)) return fail(NTM_EINVAL, "ntm_tcn_forward: T must be below 2^31 - 2^25 samples");
+    for (int l = 0; l < L; ++l)
+        if (dil[l] <= 0 || dil[l] > (1 << 20)) return fail(NTM_EINVAL, "ntm_tcn_forward: dilations must lie in [1, 2^20]");
     hipError_t e = ntm::launch_tcn(params, L, C, K, dil, x, y, B, T, scratch, (hipStream_t)stream);
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_tcn_forward");
 }

@@ -360,6 +360,16 @@ def test_bench_one_rank_process_group_runs_the_rccl_calls():
     assert out["checks"]["every_timed_step_same_loss"] is True
 
 
+def test_tcn_refuses_dilations_outside_its_32_bit_sample_arithmetic(ntm):
+    """The block kernels index samples with 32-bit arithmetic: dilations outside [1, 2^20] are refused with a message
+    (NTM_EINVAL through the C ABI), nothing is launched."""
+    x = torch.zeros(1, 1, 64, device="cuda")
+    for dil in ((1, 0), (1, (1 << 20) + 1)):
+        m = ntm.TCN(dilations=dil).to("cuda")
+        with pytest.raises(ntm._lib.NtmError, match="dilations"):
+            m(x)
+
+
 # ----------------------------------------------------------------------------- feeder, demodulated items (golden g15 c)
 def test_g15_feeder_demodulated_items_equal_reference(ntm, tmp_path):
     """VADataset(demodulate=True).__getitem__ (code/dataset.py:395-408: demodulate the 2-channel target with the
