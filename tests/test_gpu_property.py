@@ -1,0 +1,137 @@
+"""Property-style parity tests (hypothesis): the HIP path against the oracle on RANDOM shapes, chunkings, delays and
+dilations -- the cases nobody thought of writing down.  Integer / interpolation work bit for bit, the fp32 paths within
+the path's 1e-5.  All through the Python host layer, i.e. through the C ABI.  Example counts are small: every example
+is one or more kernel launches plus an oracle evaluation."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+SET = dict(deadline=None, suppress_health_check=list(HealthCheck), derandomize=True)
+
+
+@pytest.fixture(scope="module")
+def ntm():
+    import ntm_amd
+    assert torch.cuda.is_available()
+    return ntm_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ----------------------------------------------------------------------------- K2: time-varying delay line, bit-exact
+@settings(max_examples=120, **SET)
+@given(B=st.integers(1, 5), T=st.integers(1, 300), D=st.integers(1, 70), seed=st.integers(0, 2**31 - 1),
+       cuts=st.lists(st.integers(1, 299), max_size=3), integer_delays=st.booleans())
+def test_delay_line_random_shapes_and_chunkings_bit_exact(ntm, B, T, D, seed, cuts, integer_delays):
+    """code/model.py:269-320 in closed form: any batch, length (also T < D), buffer length, chunking; delays anywhere in
+    [-0.9, D] including exact integers and d = D: output and carried buffer equal the oracle's bit for bit."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, T)).astype(np.float32)
+    d = rng.uniform(-0.9, D, (B, T)).astype(np.float32)
+    if integer_delays:
+        d = np.round(d).clip(0, D).astype(np.float32)
+    d[:, rng.integers(0, T)] = D
+    buf0 = rng.standard_normal((B, D)).astype(np.float32)
+    yo, bo = oracle.delay_forward(x, d, buf0)
+    dl = ntm.TimeVaryingDelayLine(max_delay=D)
+    dl.init_buffer(B, D)
+    dl.buffer = dev(buf0).view(B, 1, D)
+    edges = [0] + sorted({c for c in cuts if c < T}) + [T]
+    ys = [dl(dev(x[:, a:b]).unsqueeze(1), dev(d[:, a:b]).unsqueeze(1)) for a, b in zip(edges, edges[1:])]
+    y = torch.cat(ys, dim=2)[:, 0].cpu().numpy()
+    assert np.array_equal(y, yo)
+    assert np.array_equal(dl.buffer[:, 0].cpu().numpy(), bo)
+
+
+# ----------------------------------------------------------------------------- K1: GRU + head, all compiled hidden sizes
+@settings(max_examples=60, **SET)
+@given(H=st.sampled_from([8, 16, 32, 64]), B=st.integers(1, 40), T=st.integers(1, 200), seed=st.integers(0, 2**31 - 1),
+       cuts=st.lists(st.integers(1, 199), max_size=2))
+def test_gru_random_shapes_hidden_sizes_and_chunkings(ntm, H, B, T, seed, cuts):
+    """RNN.forward (code/model.py:67-88) with random weights of every compiled hidden size: within 1e-5 of the oracle,
+    carried state included, and a chunked run equals the one-shot run bit for bit."""
+    rng = np.random.default_rng(seed)
+    k = 1.0 / np.sqrt(H)
+    sd = {"GRU.weight_ih_l0": rng.uniform(-k, k, (3 * H, 1)), "GRU.weight_hh_l0": rng.uniform(-k, k, (3 * H, H)),
+          "GRU.bias_ih_l0": rng.uniform(-k, k, 3 * H), "GRU.bias_hh_l0": rng.uniform(-k, k, 3 * H),
+          "output.weight": rng.uniform(-k, k, (1, H)), "output.bias": rng.uniform(-k, k, 1)}
+    sd = {n: v.astype(np.float32) for n, v in sd.items()}
+    m = ntm.RNN(1, H, 1)
+    m.load_state_dict({n: torch.from_numpy(v) for n, v in sd.items()})
+    m = m.to("cuda").eval()
+    x = rng.uniform(-0.9, 0.9, (B, T)).astype(np.float32)
+    h0 = rng.uniform(-0.5, 0.5, (B, H)).astype(np.float32)
+    w = oracle.Weights.from_state_dict(sd)
+    yo, ho = oracle.gru_forward(w, x, h0.copy())
+    m.hidden = dev(h0).view(1, B, H).clone()
+    y1 = m(dev(x).unsqueeze(1))
+    h1 = m.hidden.clone()
+    assert np.abs(y1[:, 0].cpu().numpy() - yo).max() < TOL
+    assert np.abs(h1[0].cpu().numpy() - ho).max() < TOL
+    m.hidden = dev(h0).view(1, B, H).clone()
+    edges = [0] + sorted({c for c in cuts if c < T}) + [T]
+    y2 = torch.cat([m(dev(x[:, a:b]).unsqueeze(1)) for a, b in zip(edges, edges[1:])], dim=2)
+    assert torch.equal(y1, y2) and torch.equal(h1, m.hidden)
+
+
+# ----------------------------------------------------------------------------- K4: TCN, both tilings
+DIL = st.one_of(st.integers(1, 40), st.integers(512, 700))
+
+
+@settings(max_examples=40, **SET)
+@given(B=st.integers(1, 3), T=st.integers(1, 3000), dil=st.lists(DIL, min_size=0, max_size=3), seed=st.integers(0, 1000))
+def test_tcn_random_dilations_and_lengths(ntm, B, T, dil, seed):
+    """Builder-defined TCN: random inner dilations (polyphase tiles below 512, phase-group tiles from 512 up, either as
+    inner or as last block with the fused output conv), random ragged lengths: within 1e-5 of the oracle."""
+    dil = tuple([1] + dil)
+    m = ntm.TCN(dilations=dil, seed=seed).to("cuda")
+    rng = np.random.default_rng(seed + T)
+    x = rng.uniform(-0.8, 0.8, (B, T)).astype(np.float32)
+    y = m(dev(x).unsqueeze(1)).cpu().numpy()[:, 0, :]
+    yo = oracle.tcn_forward(m.packed_params().cpu().numpy(), len(dil), 32, 13, dil, x)
+    assert np.abs(y - yo).max() < TOL
+
+
+# ----------------------------------------------------------------------------- K3: ESR sums
+@settings(max_examples=60, **SET)
+@given(B=st.integers(1, 9), T=st.integers(2, 5000), skip_frac=st.floats(0.0, 0.9), seed=st.integers(0, 2**31 - 1))
+def test_esr_sums_random_shapes(ntm, B, T, skip_frac, seed):
+    """sum (t - y)^2 and sum t^2 per stream over [skip, T): fp64 accumulation on the device, 1e-9 relative to numpy fp64."""
+    rng = np.random.default_rng(seed)
+    y = rng.standard_normal((B, T)).astype(np.float32)
+    t = rng.standard_normal((B, T)).astype(np.float32)
+    skip = int(skip_frac * (T - 1))
+    s = ntm.model.esr_sums(dev(y).unsqueeze(1), dev(t).unsqueeze(1), skip=skip).cpu().numpy()
+    so = oracle.esr_sums(y, t, skip=skip)
+    assert np.allclose(s, so, rtol=1e-9, atol=1e-12)
+
+
+# ----------------------------------------------------------------------------- N3: demodulate, bit-exact
+@settings(max_examples=40, **SET)
+@given(N=st.integers(3000, 30000), period=st.integers(200, 500), delay0=st.integers(-40, 1500), wow=st.floats(0.0, 60.0),
+       first=st.integers(0, 400), seed=st.integers(0, 2**31 - 1))
+def test_demodulate_random_pulse_trains_bit_exact(ntm, N, period, delay0, wow, first, seed):
+    """DelayAnalyzer.demodulate (code/utilities/utilities.py:408-465): random pulse period, static delay (also negative:
+    no roll), wow depth and first pulse position; the searches start from a guess, the result is the oracle's to the bit."""
+    rng = np.random.default_rng(seed)
+    x_idx = np.arange(first, N - 3 * period, period)
+    if len(x_idx) < 3:
+        return
+    dly = delay0 + wow * np.sin(2 * np.pi * 1.3 * x_idx / 44100) + 3 * np.sin(2 * np.pi * 11.0 * x_idx / 44100)
+    y_idx = np.round(x_idx + dly).astype(np.int64)
+    keep = (y_idx >= 0) & (y_idx < N)
+    x_idx, y_idx = x_idx[keep].astype(np.int64), y_idx[keep]
+    if len(y_idx) < 3 or np.any(np.diff(y_idx) <= 0):
+        return
+    out = rng.standard_normal((2, N)).astype(np.float32)
+    ref = oracle.demodulate(out, x_idx, y_idx).astype(np.float32)
+    got = ntm.feeder.demodulate(dev(out), x_idx, y_idx).cpu().numpy()
+    assert np.array_equal(got, ref)
