@@ -55,7 +55,7 @@ LAB_VARIANTS = ("mfma", "valu", "mfma3", "mfma4")
 
 _lib = None
 _lab = None
-ABI_VERSION = 2          # include/ntm.h NTM_ABI_VERSION this binding was written against
+ABI_VERSION = 3          # include/ntm.h NTM_ABI_VERSION this binding was written against
 HIDDEN_SIZES = (8, 16, 32, 64)
 
 
