@@ -52,6 +52,15 @@ int ntm_debug_gru_ablate(const float *w_ih, const float *w_hh, const float *b_ih
  * 256-thread block: in/out [256][4] floats (device). */
 int ntm_debug_transpose4(const float *in, float *out, void *stream);
 
+/* DIAGNOSTIC ONLY: ntm_tcn_forward's arguments through a build of the TCN kernels whose phase-group block kernel (inner
+ * blocks with dilation >= 512) takes s_memtime at six points of every iteration; ntm_lab_tcn_stamps copies the sums one
+ * wave accumulated to host7[0..5] (issue of the block loads, MFMA block, ring stores, epilogue, barrier, loop back-edge;
+ * clock ticks) and its iteration count to host7[6].  With NTM_LAB_TCN_ONE_WG set in the environment the launch asks
+ * for 90 KB of LDS, i.e. one workgroup per CU and one wave per SIMD.  Returns a hipError_t value (0 = success). */
+int ntm_lab_tcn_forward(const float *params, int L, int C, int K, const int *dil, const float *x, float *y, int64_t B,
+                        int64_t T, float *scratch, void *stream);
+int ntm_lab_tcn_stamps(unsigned long long *host7);
+
 #ifdef __cplusplus
 }
 #endif

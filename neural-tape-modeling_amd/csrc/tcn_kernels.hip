@@ -11,11 +11,28 @@
 // polyphase tile order + LDS staging below fetches each row once per tile: 8.3 ms per block.
 #include "ntm_common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace ntm {
 
 __device__ float tcn_zeros[16 * 32];   // zero page (one row block) for rows before the start of a stream / of no tile
+
+#ifdef NTM_LAB
+// DIAGNOSTIC build (libntm_lab.so only, never timed as product): tcn_block_pg_kernel<false> takes s_memtime at six points
+// of every iteration and one wave leaves the per-segment sums here (ntm_lab_tcn_stamps, tools/tcn_stamp_probe.py).  The
+// wait sits inside the asm: s_memtime returns asynchronously and would otherwise land in a register pair the compiler
+// has already given to something else.
+__device__ unsigned long long tcn_stamp_out[8];
+#define TCN_STAMP(k)                                                                                   \
+    if constexpr (!FUSE_OUT) {                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_[k])::"memory");                 \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+    }
+#else
+#define TCN_STAMP(k)
+#endif
 
 constexpr int TCN_PAD_FLOATS = 16 * 32;   // behind each activation buffer: a row block may reach 15 rows past T (read, never used)
 
@@ -375,7 +392,9 @@ __global__ __launch_bounds__(256, 2) void tcn_block_pg_kernel(const float *in, f
                                                               const float *obias, float *yout)
 {
     extern __shared__ __attribute__((aligned(16))) float tsm[];
-    __shared__ float ypp[2][2][2][16];        // FUSE_OUT: [iteration parity][pair][tile][sample] partial of wave mt = 1
+    // FUSE_OUT: the lanes' output-conv partials, [iteration parity][pair][tile][sample j][mt * 4 + q] (the 8 partials of a
+    // sample are 32 contiguous bytes)
+    __shared__ __attribute__((aligned(16))) float ypp[2][2][2][16][8];
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mt = w & 1, ng = w >> 1;
@@ -403,8 +422,6 @@ __global__ __launch_bounds__(256, 2) void tcn_block_pg_kernel(const float *in, f
 #pragma unroll
         for (int v = 0; v < 4; ++v) owv[v] = ow[16 * mt + 4 * q + v];
     }
-    float ypart[2] = {0.0f, 0.0f};
-    int yn[2] = {T, T};
     float *yb = FUSE_OUT ? yout + b * T64 : nullptr;
     const float ob0 = FUSE_OUT ? obias[0] : 0.0f;
 
@@ -441,12 +458,16 @@ __global__ __launch_bounds__(256, 2) void tcn_block_pg_kernel(const float *in, f
     // touches depend only on PH = it & 7: the loop is unrolled over the 8 phases and every LDS address is the lane's
     // base register + an immediate (the rolled form needed a v_add per block -- 17 of the ~100 vector instructions
     // per iteration, and a vector instruction of either wave on a SIMD costs ~8 matrix-pipe cycles).
+    unsigned long long seg_[6] = {0, 0, 0, 0, 0, 0}, last_ = 0, ts_[6];
+    (void)seg_; (void)last_; (void)ts_;
     auto iteration = [&](const int it, auto ph_c) {
         constexpr int PH = decltype(ph_c)::value;
         constexpr int S0 = 2 * PH;                        // slot of row block m0
         const int m0 = 2 * it;
+        TCN_STAMP(0)
         const f32x4 nb0 = block_load(m0 + 2), nb1 = block_load(m0 + 3);     // the next iteration's new blocks
         __builtin_amdgcn_sched_barrier(0);
+        TCN_STAMP(1)   // block loads issued
         f32x4 acc[2], res[2];
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) { acc[nt] = bi; res[nt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f}; }
@@ -479,30 +500,42 @@ __global__ __launch_bounds__(256, 2) void tcn_block_pg_kernel(const float *in, f
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef PG_READ
+        TCN_STAMP(2)   // MFMA block (14 row blocks)
         // new row blocks -> ring BEFORE the epilogue's global stores (see tcn_block_mfma2_kernel); their slots are
         // those of blocks m0 - 14, m0 - 13, which no tile of this iteration reads
         *(f32x4 *)(st_lds + ((S0 + 2) & (PG_SLOTS - 1)) * PG_BLK_F) = nb0;
         *(f32x4 *)(st_lds + ((S0 + 3) & (PG_SLOTS - 1)) * PG_BLK_F) = nb1;
+        TCN_STAMP(3)   // ring stores (vmcnt wait)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int n0 = g16 + (m0 + nt) * dil;          // first sample of the tile's row block
             const int rem = T - n0;                         // rows left up to T (<= 0: none)
             const f32x4 v = prelu_plus(acc[nt], al, res[nt]);
             if constexpr (FUSE_OUT) {
-                const float pp = sum_lane_groups(dot4(owv, v));
-                if (mt == 1) { if (q == 0) ypp[PH & 1][ng][nt][j] = pp; }
-                else { ypart[nt] = pp; yn[nt] = jrow < rem ? n0 + j : T; }
+                // fused 1x1 output conv: every lane parks its partial over its 4 channels in LDS (no cross-lane
+                // arithmetic here: that was 6 vector instructions per tile in BOTH waves); the sums follow the barrier
+                ypp[PH & 1][ng][nt][j][mt * 4 + q] = dot4(owv, v);
             } else {
                 if (jrow < rem) *(f32x4 *)((char *)(ob + (int64_t)n0 * TC) + offS) = v;
             }
         }
+        TCN_STAMP(4)   // epilogue
         __syncthreads();
-        if constexpr (FUSE_OUT) {                          // wave mt = 0 adds the other half and stores
-            if (mt == 0 && q == 0) {
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
-                    if (yn[nt] < T) *(float *)((char *)yb + 4u * (unsigned)yn[nt]) = (ypart[nt] + ypp[PH & 1][ng][nt][j]) + ob0;
-            }
+        TCN_STAMP(5)   // barrier
+#ifdef NTM_LAB
+        if constexpr (!FUSE_OUT) {
+            for (int i = 0; i < 5; ++i) seg_[i] += ts_[i + 1] - ts_[i];
+            if (it > 0) seg_[5] += ts_[0] - last_;      // loop back-edge
+            last_ = ts_[5];
+        }
+#endif
+        if constexpr (FUSE_OUT) {
+            // wave mt finishes tile nt = mt: the 8 partials of sample j (two ds_read_b128), summed in a fixed order,
+            // 16 consecutive samples = one 64-byte store by the lanes q = 0
+            const int n0 = g16 + (m0 + mt) * dil, rem = T - n0;
+            const f32x4 pa = *(const f32x4 *)&ypp[PH & 1][ng][mt][j][0], pb = *(const f32x4 *)&ypp[PH & 1][ng][mt][j][4];
+            const float ysum = (((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pb[0] + pb[1]) + (pb[2] + pb[3]))) + ob0;
+            if (q == 0 && jrow < rem) *(float *)((char *)(yb + n0) + 4 * j) = ysum;
         }
     };
     for (int it = 0; it < niter; it += 8) {
@@ -522,6 +555,12 @@ __global__ __launch_bounds__(256, 2) void tcn_block_pg_kernel(const float *in, f
         if (it + 7 >= niter) break;
         iteration(it + 7, IntC<7>{});
     }
+#ifdef NTM_LAB
+    if (!FUSE_OUT && blockIdx.x == 7 && blockIdx.y == 3 && tid == 0) {
+        for (int i = 0; i < 6; ++i) tcn_stamp_out[i] = seg_[i];
+        tcn_stamp_out[6] = (unsigned long long)niter;
+    }
+#endif
 }
 
 // ---- 1x1 output conv: [B][T][32] -> y [B][T] --------------------------------------------------------
@@ -571,7 +610,10 @@ hipError_t launch_tcn(const float *params, int L, int C, int K, const int *dil, 
                 // large dilation: phase-group tiles with a sliding window (two groups per workgroup)
                 const int groups = (dil[l] + 15) / 16;
                 const dim3 gridg((unsigned)B, (unsigned)((groups + 1) / 2));
-                const size_t smem = PG_SMEM_FLOATS * sizeof(float);
+                size_t smem = PG_SMEM_FLOATS * sizeof(float);
+#ifdef NTM_LAB
+                if (getenv("NTM_LAB_TCN_ONE_WG")) smem = 90 * 1024;       // diagnostic: one workgroup per CU, one wave per SIMD
+#endif
                 if (l == L - 1) {
                     auto k = tcn_block_pg_kernel<true>;
                     hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -611,3 +653,16 @@ hipError_t launch_tcn(const float *params, int L, int C, int K, const int *dil, 
 }
 
 }  // namespace ntm
+
+#ifdef NTM_LAB
+// laboratory entry points (include/ntm_lab.h): the same forward through the STAMP build, and its segment sums
+extern "C" int ntm_lab_tcn_forward(const float *params, int L, int C, int K, const int *dil, const float *x, float *y, int64_t B,
+                                   int64_t T, float *scratch, void *stream)
+{
+    return (int)ntm::launch_tcn(params, L, C, K, dil, x, y, B, T, scratch, (hipStream_t)stream);
+}
+extern "C" int ntm_lab_tcn_stamps(unsigned long long *host7)
+{
+    return (int)hipMemcpyFromSymbol(host7, HIP_SYMBOL(ntm::tcn_stamp_out), 7 * sizeof(unsigned long long));
+}
+#endif
