@@ -135,3 +135,30 @@ def test_demodulate_random_pulse_trains_bit_exact(ntm, N, period, delay0, wow, f
     ref = oracle.demodulate(out, x_idx, y_idx).astype(np.float32)
     got = ntm.feeder.demodulate(dev(out), x_idx, y_idx).cpu().numpy()
     assert np.array_equal(got, ref)
+
+
+# ----------------------------------------------------------------------------- K1: dispatch boundaries of NTM_GRU_AUTO
+@pytest.mark.parametrize("B", [1023, 1024, 1025, 4095, 4096, 4097, 4111, 4112, 4113, 5120, 6144, 8191, 8192, 8193, 12288])
+def test_gru_auto_dispatch_boundaries(ntm, B):
+    """kernel_variant="auto" around every batch size where the dispatch changes (low-latency kernel up to 1024 streams,
+    one device round of the matrix-pipe kernel + remainder, several groups per CU, the small-LDS build from 8192): all
+    streams against the oracle for tile-edge lengths, carried state included, chunked == one-shot bit for bit."""
+    from helpers import oracle_weights
+    w = oracle_weights(ntm.weights.W_GRU)
+    m = ntm.harness.build_model(ntm.weights.W_GRU)
+    m.kernel_variant = "auto"
+    rng = np.random.default_rng(B)
+    for T in (1, 63, 64, 65, 129):
+        x = rng.uniform(-0.7, 0.7, (B, T)).astype(np.float32)
+        h0 = rng.uniform(-0.3, 0.3, (B, 64)).astype(np.float32)
+        yo, ho = oracle.gru_forward(w, x, h0.copy(), threads=8)
+        m.hidden = dev(h0).view(1, B, 64).clone()
+        y = m(dev(x).unsqueeze(1))
+        h = m.hidden.clone()
+        assert np.abs(y[:, 0].cpu().numpy() - yo).max() < TOL, (B, T)
+        assert np.abs(h[0].cpu().numpy() - ho).max() < TOL, (B, T)
+        if T > 1:
+            m.hidden = dev(h0).view(1, B, 64).clone()
+            c = T // 2
+            y2 = torch.cat([m(dev(x[:, :c]).unsqueeze(1)), m(dev(x[:, c:]).unsqueeze(1))], dim=2)
+            assert torch.equal(y, y2) and torch.equal(h, m.hidden), (B, T)
