@@ -162,3 +162,32 @@ def test_gru_auto_dispatch_boundaries(ntm, B):
             c = T // 2
             y2 = torch.cat([m(dev(x[:, :c]).unsqueeze(1)), m(dev(x[:, c:]).unsqueeze(1))], dim=2)
             assert torch.equal(y, y2) and torch.equal(h, m.hidden), (B, T)
+
+
+# ----------------------------------------------------------------------------- DiffDelGRU.predict, random delay trajectories
+@settings(max_examples=20, **SET)
+@given(B=st.integers(1, 12), T=st.integers(1, 2500), delay_s=st.floats(0.0005, 0.02), wow=st.floats(0.0, 0.3),
+       seed=st.integers(0, 2**31 - 1), chunk=st.sampled_from([None, 256, 2048]))
+def test_diffdel_predict_random_batches_and_trajectories(ntm, B, T, delay_s, wow, seed, chunk):
+    """DiffDelRNN.predict (code/model.py:618-653; batched): random batch, length, model max_delay and wow depth; y and pre_d
+    within 1e-5 of the oracle, y exactly the oracle's delay line applied to the device's own pre_d (bit for bit), and the
+    reference's 2048-sample chunk loop (`segment_length`) equal to the single launch bit for bit."""
+    from helpers import oracle_weights
+    from test_gpu_parity import W_D
+    fs = 44100
+    m = ntm.harness.build_model(W_D, max_delay_seconds=delay_s)
+    D = m.max_delay
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-0.6, 0.6, (B, T)).astype(np.float32)
+    n = np.arange(T)
+    base = delay_s * fs * rng.uniform(0.3, 0.9, (B, 1))
+    d = base * (1.0 + wow * np.sin(2 * np.pi * rng.uniform(0.5, 3.0, (B, 1)) * n / fs + rng.uniform(0, 6.28, (B, 1))))
+    d = np.clip(d, 0.0, D).astype(np.float32)
+    kw = {} if chunk is None else {"segment_length": chunk}
+    y, pre = m.predict(dev(x).unsqueeze(1), dev(d).unsqueeze(1), **kw)
+    yo, preo, _, _ = oracle.diffdel_predict(oracle_weights(W_D), x, d, D, threads=4)
+    assert np.abs(pre[:, 0].cpu().numpy() - preo).max() < TOL
+    assert np.abs(y[:, 0].cpu().numpy() - yo).max() < TOL
+    if chunk is not None:
+        y1, pre1 = m.predict(dev(x).unsqueeze(1), dev(d).unsqueeze(1))
+        assert torch.equal(y, y1) and torch.equal(pre, pre1)
