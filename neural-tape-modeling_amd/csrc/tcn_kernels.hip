@@ -175,7 +175,7 @@ __device__ __forceinline__ float sum_lane_groups(float p)
     return p + t;
 }
 
-// ---- 32 -> 32 channel block, polyphase tile order + LDS staging (the one launch_tcn uses) -------------
+// ---- 32 -> 32 channel block, polyphase tile order + LDS staging (dilations below 512) ----------------
 // A tile is 16 outputs of ONE phase of the dilation: n = p + (m0 + j) dil, j = 0..15.  Its 13 taps read the
 // rows m0 + j + k - 12 of the same phase, so consecutive taps reuse the same 28 input rows: they are staged
 // once in LDS (register-staged one iteration ahead) and the B operands of all 13 x 8 K-steps are
