@@ -39,8 +39,32 @@ struct StftArgs {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ f2 cmul(f2 a, f2 b) { return (f2){a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+// Complex arithmetic on packed fp32 pairs with the operand-select / negate modifiers of the VOP3P encoding written out:
+// hipcc builds a complex product from v_pk_mul + TWO v_pk_fma (one per sign pattern) + a v_mov that splices their halves,
+// and a multiplication by -i from v_xor + v_mov -- 90 of the ~660 vector instructions of a 1024-point frame pair, in a
+// kernel that is bound by vector issue.
+__device__ __forceinline__ f2 cmul(f2 a, f2 b)
+{
+    f2 r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));                     // (ax bx, ax by)
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"             // (- ay by, + ay bx)
+        : "+v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ f2 mul_mi(f2 a) { return (f2){a.y, -a.x}; }             // a * (-i)
+// a + (-i) d  and  a - (-i) d  in one packed add each (the half swap and the sign ride on the second operand)
+__device__ __forceinline__ f2 add_mi(f2 a, f2 d)
+{
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(d));   // (a.x + d.y, a.y - d.x)
+    return r;
+}
+__device__ __forceinline__ f2 sub_mi(f2 a, f2 d)
+{
+    f2 r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(d));   // (a.x - d.y, a.y + d.x)
+    return r;
+}
 
 __device__ __forceinline__ void wave_lds_fence()
 {
@@ -54,8 +78,15 @@ __device__ __forceinline__ void dft2(f2 &a, f2 &b) { const f2 t = a; a = t + b; 
 
 __device__ __forceinline__ void dft4(f2 &x0, f2 &x1, f2 &x2, f2 &x3)
 {
-    const f2 s02 = x0 + x2, d02 = x0 - x2, s13 = x1 + x3, jd = mul_mi(x1 - x3);
-    x0 = s02 + s13; x1 = d02 + jd; x2 = s02 - s13; x3 = d02 - jd;
+    const f2 s02 = x0 + x2, d02 = x0 - x2, s13 = x1 + x3, d13 = x1 - x3;
+    x0 = s02 + s13; x1 = add_mi(d02, d13); x2 = s02 - s13; x3 = sub_mi(d02, d13);
+}
+
+// the same with x2 standing for (-i) x2 (the W16^4 twiddle of the radix-16 butterfly, folded into the first adds)
+__device__ __forceinline__ void dft4_x2mi(f2 &x0, f2 &x1, f2 &x2, f2 &x3)
+{
+    const f2 s02 = add_mi(x0, x2), d02 = sub_mi(x0, x2), s13 = x1 + x3, d13 = x1 - x3;
+    x0 = s02 + s13; x1 = add_mi(d02, d13); x2 = s02 - s13; x3 = sub_mi(d02, d13);
 }
 
 constexpr float C8 = 0.70710678118654752f;                       // cos(pi/4)
@@ -71,12 +102,15 @@ template <> __device__ __forceinline__ void dft<8>(f2 (&x)[8])
 {
     dft4(x[0], x[2], x[4], x[6]);                                 // n2 = 0: a[0][k1] in x[2 k1]
     dft4(x[1], x[3], x[5], x[7]);                                 // n2 = 1: a[1][k1] in x[2 k1 + 1]
-    x[3] = (f2){C8 * (x[3].x + x[3].y), C8 * (x[3].y - x[3].x)};  // * W8^1 = (c, -c)
-    x[5] = mul_mi(x[5]);                                          // * W8^2
-    x[7] = (f2){C8 * (x[7].y - x[7].x), -C8 * (x[7].x + x[7].y)}; // * W8^3 = (-c, -c)
+    x[3] = add_mi(x[3], x[3]) * (f2){C8, C8};                     // * W8^1 = (c, -c):  c (x + y, y - x)
+    // (x[5] * W8^2 = x[5] * (-i) is folded into the last stage below)
+    x[7] = sub_mi(x[7], x[7]) * (f2){-C8, -C8};                   // * W8^3 = (-c, -c): -c (x - y, x + y)
     f2 y[8];
 #pragma unroll
-    for (int k1 = 0; k1 < 4; ++k1) { y[k1] = x[2 * k1] + x[2 * k1 + 1]; y[k1 + 4] = x[2 * k1] - x[2 * k1 + 1]; }
+    for (int k1 = 0; k1 < 4; ++k1) {
+        if (k1 == 2) { y[k1] = add_mi(x[4], x[5]); y[k1 + 4] = sub_mi(x[4], x[5]); }
+        else { y[k1] = x[2 * k1] + x[2 * k1 + 1]; y[k1 + 4] = x[2 * k1] - x[2 * k1 + 1]; }
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) x[i] = y[i];
 }
@@ -89,10 +123,13 @@ template <> __device__ __forceinline__ void dft<16>(f2 (&x)[16])
     // twiddles W16^(n2 k1)
     const f2 w1 = {C16, -S16}, w2 = {C8, -C8}, w3 = {S16, -C16}, w6 = {-C8, -C8}, w9 = {-C16, S16};
     x[4 * 1 + 1] = cmul(x[4 * 1 + 1], w1); x[4 * 1 + 2] = cmul(x[4 * 1 + 2], w2); x[4 * 1 + 3] = cmul(x[4 * 1 + 3], w3);
-    x[4 * 2 + 1] = cmul(x[4 * 2 + 1], w2); x[4 * 2 + 2] = mul_mi(x[4 * 2 + 2]);   x[4 * 2 + 3] = cmul(x[4 * 2 + 3], w6);
+    x[4 * 2 + 1] = cmul(x[4 * 2 + 1], w2); /* x[10] * (-i): inside dft4_x2mi below */ x[4 * 2 + 3] = cmul(x[4 * 2 + 3], w6);
     x[4 * 3 + 1] = cmul(x[4 * 3 + 1], w3); x[4 * 3 + 2] = cmul(x[4 * 3 + 2], w6); x[4 * 3 + 3] = cmul(x[4 * 3 + 3], w9);
 #pragma unroll
-    for (int k1 = 0; k1 < 4; ++k1) dft4(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);   // X[k1 + 4 k2] in x[4 k1 + k2]
+    for (int k1 = 0; k1 < 4; ++k1) {                                                              // X[k1 + 4 k2] in x[4 k1 + k2]
+        if (k1 == 2) dft4_x2mi(x[8], x[9], x[10], x[11]);
+        else dft4(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);
+    }
     f2 y[16];
 #pragma unroll
     for (int k1 = 0; k1 < 4; ++k1)
