@@ -52,6 +52,14 @@ __device__ __forceinline__ f2 cmul(f2 a, f2 b)
     return r;
 }
 __device__ __forceinline__ f2 mul_mi(f2 a) { return (f2){a.y, -a.x}; }             // a * (-i)
+// The two real spectra inside Z = FFT(y + i t), UNSCALED:  2 Y[k] = Z[k] + conj Z[N-k],  2 T[k] = (Z[k] - conj Z[N-k]) / i,
+// one packed add each.  (The factor 1/2 -- 1/4 on the powers -- is a power of two: it is applied once to the frame
+// sums, with the clamp floor scaled the other way; results are bit-identical to scaling every bin.)
+__device__ __forceinline__ void split_spectra(f2 zk, f2 zn, f2 &Y2, f2 &T2)
+{
+    asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(Y2) : "v"(zk), "v"(zn));                                   // (zk.x + zn.x, zk.y - zn.y)
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(T2) : "v"(zk), "v"(zn));      // (zk.y + zn.y, zn.x - zk.x)
+}
 // a + (-i) d  and  a - (-i) d  in one packed add each (the half swap and the sign ride on the second operand)
 __device__ __forceinline__ f2 add_mi(f2 a, f2 d)
 {
@@ -257,6 +265,7 @@ __global__ __launch_bounds__(256, (LOG2N <= 10 ? 2 : 1)) void stft_sums_kernel(S
     constexpr int FSTEP = 4 * FPW;                             // frames per workgroup and iteration
 
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const float eps4 = 4.0f * a.eps;                           // floor of the unscaled (4 x) powers, see split_spectra
     // raw samples of the frame pair, fetched one frame ahead: ry/rt[q] = (y, t)[f hop + sl + SUB q - N/2],
     // reflected at the ends (torch.stft center=True, pad_mode="reflect"); frame slots past the end read frame 0
     float ry[P], rt[P];
@@ -301,10 +310,11 @@ __global__ __launch_bounds__(256, (LOG2N <= 10 ? 2 : 1)) void stft_sums_kernel(S
         float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
         auto bin = [&](int k) {
             const f2 zk = buf[padi(k)], zn = buf[padi((N - k) & (N - 1))];
-            const float yr = 0.5f * (zk.x + zn.x), yi = 0.5f * (zk.y - zn.y);
-            const float tr = 0.5f * (zk.y + zn.y), ti = 0.5f * (zn.x - zk.x);
-            const float py0 = yr * yr + yi * yi, pt0 = tr * tr + ti * ti;
-            const float py = fmaxf(py0, a.eps), pt = fmaxf(pt0, a.eps);
+            f2 Y2, T2;
+            split_spectra(zk, zn, Y2, T2);
+            const f2 ysq = Y2 * Y2, tsq = T2 * T2;
+            const float py0 = ysq.x + ysq.y, pt0 = tsq.x + tsq.y;                 // 4 x the powers
+            const float py = fmaxf(py0, eps4), pt = fmaxf(pt0, eps4);
             if constexpr (MODE == 0) {
                 // auraloss.freq.STFTLoss terms: magnitudes sqrt(clamp(power, eps))
                 const float my = __builtin_amdgcn_sqrtf(py), mt = __builtin_amdgcn_sqrtf(pt);
@@ -337,10 +347,11 @@ __global__ __launch_bounds__(256, (LOG2N <= 10 ? 2 : 1)) void stft_sums_kernel(S
             float py_[P / 2], pt_[P / 2], pyn = 0.0f, ptn = 0.0f;
             auto power = [&](int k, float &py0, float &pt0) {
                 const f2 zk = buf[padi(k)], zn = buf[padi((N - k) & (N - 1))];
-                const float yr = 0.5f * (zk.x + zn.x), yi = 0.5f * (zk.y - zn.y);
-                const float tr = 0.5f * (zk.y + zn.y), ti = 0.5f * (zn.x - zk.x);
-                py0 = yr * yr + yi * yi;
-                pt0 = tr * tr + ti * ti;
+                f2 Y2, T2;
+                split_spectra(zk, zn, Y2, T2);
+                const f2 ysq = Y2 * Y2, tsq = T2 * T2;
+                py0 = ysq.x + ysq.y;                                              // 4 x the powers
+                pt0 = tsq.x + tsq.y;
             };
 #pragma unroll
             for (int i = 0; i < P / 2; ++i) power(sl + SUB * i, py_[i], pt_[i]);
@@ -361,7 +372,7 @@ __global__ __launch_bounds__(256, (LOG2N <= 10 ? 2 : 1)) void stft_sums_kernel(S
                         mt = __builtin_fmaf(wq, pw[N / 2 + 1 + b0 + q], mt);
                     }
                     s0 += fabsf(my - mt);
-                    s1 += fabsf(__builtin_amdgcn_logf(fmaxf(my, a.eps)) - __builtin_amdgcn_logf(fmaxf(mt, a.eps)));
+                    s1 += fabsf(__builtin_amdgcn_logf(fmaxf(my, eps4)) - __builtin_amdgcn_logf(fmaxf(mt, eps4)));
                     s2 += mt;
                     s3 += my;
                 }
@@ -371,6 +382,9 @@ __global__ __launch_bounds__(256, (LOG2N <= 10 ? 2 : 1)) void stft_sums_kernel(S
         wave_lds_fence();
     }
     // mode 0: |ln mag_y - ln mag_t| = (ln 2 / 2) |log2 p_y - log2 p_t|;  mode 1: log10 = log10(2) log2
+    // undo the factor 4 of the powers (2 of the magnitudes); the log differences do not carry it
+    if constexpr (MODE == 0) { acc[0] *= 0.25; acc[1] *= 0.25; acc[3] *= 0.5; }
+    else { acc[0] *= 0.25; acc[2] *= 0.25; acc[3] *= 0.25; }
     if constexpr (MODE == 0) acc[2] *= 0.34657359027997264;
     else acc[1] *= 0.30102999566398120;                       // modes 1 and 2: log10 = log10(2) log2
 #pragma unroll
