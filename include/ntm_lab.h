@@ -55,11 +55,15 @@ int ntm_debug_transpose4(const float *in, float *out, void *stream);
 /* DIAGNOSTIC ONLY: ntm_tcn_forward's arguments through a build of the TCN kernels whose phase-group block kernel (inner
  * blocks with dilation >= 512) takes s_memtime at six points of every iteration; ntm_lab_tcn_stamps copies the sums one
  * wave accumulated to host7[0..5] (issue of the block loads, MFMA block, ring stores, epilogue, barrier, loop back-edge;
- * clock ticks) and its iteration count to host7[6].  With NTM_LAB_TCN_ONE_WG set in the environment the launch asks
+ * clock ticks) and its iteration count to host7[6]; host7 must hold 8 + 3 * 64 words: from [8] on, per iteration, the
+ * start (cycles since kernel entry), the duration of the MFMA block and of the whole iteration.  With NTM_LAB_TCN_ONE_WG set in the environment the launch asks
  * for 90 KB of LDS, i.e. one workgroup per CU and one wave per SIMD.  Returns a hipError_t value (0 = success). */
 int ntm_lab_tcn_forward(const float *params, int L, int C, int K, const int *dil, const float *x, float *y, int64_t B,
                         int64_t T, float *scratch, void *stream);
 int ntm_lab_tcn_stamps(unsigned long long *host7);
+/* device buffer of 4 words per workgroup of the stamped launch (s_memtime at start and end, XCC_ID << 32 | HW_ID, cycles
+ * inside the iteration loop), or NULL to switch the trace off */
+int ntm_lab_tcn_trace(unsigned long long *device_buf);
 
 #ifdef __cplusplus
 }

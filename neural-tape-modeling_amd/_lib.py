@@ -52,6 +52,7 @@ _LAB_SIGNATURES = {
     "ntm_debug_gru_ablate": (_int, [_vp] * 6 + [_vp, _vp, _i64, _i64, _vp, _int, _vp]),
     "ntm_lab_tcn_forward": (_int, [_vp, _int, _int, _int, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "ntm_lab_tcn_stamps": (_int, [_vp]),
+    "ntm_lab_tcn_trace": (_int, [_vp]),
 }
 LAB_VARIANTS = ("mfma", "valu", "mfma3", "mfma4")
 

@@ -23,7 +23,8 @@ __device__ float tcn_zeros[16 * 32];   // zero page (one row block) for rows bef
 // of every iteration and one wave leaves the per-segment sums here (ntm_lab_tcn_stamps, tools/tcn_stamp_probe.py).  The
 // wait sits inside the asm: s_memtime returns asynchronously and would otherwise land in a register pair the compiler
 // has already given to something else.
-__device__ unsigned long long tcn_stamp_out[8];
+__device__ unsigned long long tcn_stamp_out[8 + 3 * 64];   // [0..5] segment sums, [6] iterations, then per iteration: start, MFMA block, total
+__device__ unsigned long long *tcn_trace_buf;       // optional: 4 words per workgroup (start, end, XCC | HW_ID, cycles in the loop)
 #define TCN_STAMP(k)                                                                                   \
     if constexpr (!FUSE_OUT) {                                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                             \
@@ -396,6 +397,10 @@ __global__ __launch_bounds__(256, 2) void tcn_block_pg_kernel(const float *in, f
     // sample are 32 contiguous bytes)
     __shared__ __attribute__((aligned(16))) float ypp[2][2][2][16][8];
     const int tid = threadIdx.x, l = tid & 63;
+#ifdef NTM_LAB
+    unsigned long long t_begin_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_begin_)::"memory");
+#endif
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int mt = w & 1, ng = w >> 1;
     const int q = l >> 4, j = l & 15;
@@ -527,6 +532,11 @@ __global__ __launch_bounds__(256, 2) void tcn_block_pg_kernel(const float *in, f
             for (int i = 0; i < 5; ++i) seg_[i] += ts_[i + 1] - ts_[i];
             if (it > 0) seg_[5] += ts_[0] - last_;      // loop back-edge
             last_ = ts_[5];
+            if (blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && tid == 0 && it < 64) {
+                tcn_stamp_out[8 + 3 * it] = ts_[0] - t_begin_;
+                tcn_stamp_out[8 + 3 * it + 1] = ts_[2] - ts_[1];
+                tcn_stamp_out[8 + 3 * it + 2] = ts_[5] - ts_[0];
+            }
         }
 #endif
         if constexpr (FUSE_OUT) {
@@ -556,9 +566,18 @@ __global__ __launch_bounds__(256, 2) void tcn_block_pg_kernel(const float *in, f
         iteration(it + 7, IntC<7>{});
     }
 #ifdef NTM_LAB
-    if (!FUSE_OUT && blockIdx.x == 7 && blockIdx.y == 3 && tid == 0) {
+    if (!FUSE_OUT && blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && tid == 0) {     // a workgroup from the middle of the launch
         for (int i = 0; i < 6; ++i) tcn_stamp_out[i] = seg_[i];
         tcn_stamp_out[6] = (unsigned long long)niter;
+    }
+    if (!FUSE_OUT && tid == 0 && tcn_trace_buf) {
+        unsigned long long t_end;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end)::"memory");
+        unsigned long long *tr = tcn_trace_buf + 4 * ((size_t)blockIdx.x + (size_t)gridDim.x * blockIdx.y);
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        unsigned long long loop = 0;
+        for (int i = 0; i < 6; ++i) loop += seg_[i];
+        tr[0] = t_begin_; tr[1] = t_end; tr[2] = ((unsigned long long)xcc << 32) | hw; tr[3] = loop;
     }
 #endif
 }
@@ -661,8 +680,12 @@ extern "C" int ntm_lab_tcn_forward(const float *params, int L, int C, int K, con
 {
     return (int)ntm::launch_tcn(params, L, C, K, dil, x, y, B, T, scratch, (hipStream_t)stream);
 }
-extern "C" int ntm_lab_tcn_stamps(unsigned long long *host7)
+extern "C" int ntm_lab_tcn_trace(unsigned long long *device_buf)      // nullptr: off; else 4 words per workgroup of the stamped launch
 {
-    return (int)hipMemcpyFromSymbol(host7, HIP_SYMBOL(ntm::tcn_stamp_out), 7 * sizeof(unsigned long long));
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(ntm::tcn_trace_buf), &device_buf, sizeof(device_buf));
+}
+extern "C" int ntm_lab_tcn_stamps(unsigned long long *host7)      // 8 + 3 * 64 words
+{
+    return (int)hipMemcpyFromSymbol(host7, HIP_SYMBOL(ntm::tcn_stamp_out), (8 + 3 * 64) * sizeof(unsigned long long));
 }
 #endif

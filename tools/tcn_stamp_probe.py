@@ -27,11 +27,13 @@ for _ in range(2):
     rc = lab.ntm_lab_tcn_forward(ptr(params), 3, 32, 13, dil, ptr(x), ptr(y), B, T, ptr(scratch), _lib.current_stream())
     assert rc == 0, rc
 torch.cuda.synchronize()
-buf = (ctypes.c_ulonglong * 7)()
+buf = (ctypes.c_ulonglong * (8 + 3 * 64))()
 assert lab.ntm_lab_tcn_stamps(buf) == 0
 v = list(buf)
 names = ["issue block loads", "MFMA block (224 MFMAs)", "ring stores (vmcnt wait)", "epilogue", "barrier", "loop back-edge"]
 n = v[6]
 print(json.dumps({"one_wave_per_simd": bool(os.environ.get("NTM_LAB_TCN_ONE_WG")), "iterations": n,
                   "ticks_per_iteration": {k: round(v[i] / n, 1) for i, k in enumerate(names)}, "total": round(sum(v[:6]) / n, 1),
+                  "first_iteration_starts_at": v[8], "iteration_cycles": [v[8 + 3 * i + 2] for i in range(n)],
+                  "mfma_block_cycles": [v[8 + 3 * i + 1] for i in range(n)],
                   "y_vs_product_max_abs": float((y - m(x.view(B, 1, T)).view(B, T)).abs().max())}))
