@@ -104,74 +104,96 @@ def cpu_baseline(w_name):
     return res
 
 
-def side_workload(a):
-    """BASELINE configs[2] (DiffDelGRU-HS[64], CHOWTAPE_WOWFLUTTER weights) and configs[3] (TCN contrast
-    point) at the same batch; single GPU, not the headline metric.  Like the headline line, the JSON carries the
-    roofline of the dominant kernel with its event-timed launch duration (`roofline.kernel`, `kernel_ms`); for the
-    DiffDelGRU step the HBM roofline of the delay-line pass (K2) sits beside it as `roofline.delay_line`."""
+TCN_FLOP_PER_SAMPLE = 2 * (13 * 32 + 32 + 3 * (32 * 13 * 32 + 32 * 32) + 32)     # 43 488 FMA per sample
+
+
+def delay_trajectories(B, T, dev, max_delay):
+    """d_b[n] = fs (0.0271 + a_b sin(2 pi w_b n/fs + psi_b) + 0.0005 sin(2 pi 23 n/fs)) samples,
+    a_b in U(0.002, 0.005) s, w_b in U(0.5, 2) Hz (wow) plus a 23 Hz flutter line; clamped to [0, max_delay]."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(77)
+    amp = 0.002 + 0.003 * torch.rand(B, 1, generator=g, device=dev)
+    wv = 0.5 + 1.5 * torch.rand(B, 1, generator=g, device=dev)
+    psi = 2 * np.pi * torch.rand(B, 1, generator=g, device=dev)
+    n = torch.arange(T, device=dev, dtype=torch.float32).unsqueeze(0)
+    d = torch.empty(B, T, device=dev)
+    for b0 in range(0, B, 256):
+        sl = slice(b0, min(B, b0 + 256))
+        d[sl] = FS * (0.0271 + amp[sl] * torch.sin(2 * np.pi * wv[sl] * n / FS + psi[sl])
+                      + 0.0005 * torch.sin(2 * np.pi * 23 * n / FS))
+    return d.clamp_(0, max_delay).unsqueeze(1)
+
+
+def measure_workload(workload, B, T, steps, warmup, check, dev, threads=1):
+    """One single-GPU workload beside the headline, `steps` timed passes over a resident batch of B distinct streams:
+      "diffdel"  BASELINE configs[2]: DiffDelGRU-HS[64] (CHOWTAPE_WOWFLUTTER weights, D = 1847) predict
+      "tcn"      BASELINE configs[3]: the TCN contrast point
+      "gru"      the headline's model at another batch size -- the per-GPU shapes of configs[4]'s strong-scaling legs
+    -> dict with the whole-pass rate, the dominant kernel's event-timed launch duration and roofline, determinism of the
+    output and -- when `check` (the CPU leg; the oracle is the checker, never the thing measured) -- scattered streams
+    against the C oracle over the whole sequence."""
     import ntm_amd
     from ntm_amd import weights
-    assert torch.cuda.is_available()
-    dev = torch.device("cuda", 0)
-    B, T = a.batch, a.samples
     x = synth_input(B, T, dev, seed=1234)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     kev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    if a.workload == "diffdel":
+    d = None
+    if workload == "diffdel":
         model = ntm_amd.harness.build_model(weights.W_DIFFDEL, max_delay_seconds=0.0335, device=dev)   # D = 1847
-        g = torch.Generator(device=dev); g.manual_seed(77)
-        amp = 0.002 + 0.003 * torch.rand(B, 1, generator=g, device=dev)
-        wv = 0.5 + 1.5 * torch.rand(B, 1, generator=g, device=dev)
-        psi = 2 * np.pi * torch.rand(B, 1, generator=g, device=dev)
-        n = torch.arange(T, device=dev, dtype=torch.float32).unsqueeze(0)
-        d = torch.empty(B, T, device=dev)
-        for b0 in range(0, B, 256):
-            sl = slice(b0, min(B, b0 + 256))
-            d[sl] = FS * (0.0271 + amp[sl] * torch.sin(2 * np.pi * wv[sl] * n / FS + psi[sl])
-                          + 0.0005 * torch.sin(2 * np.pi * 23 * n / FS))
-        d = d.clamp_(0, model.max_delay).unsqueeze(1)
+        d = delay_trajectories(B, T, dev, model.max_delay)
         run = lambda: model.predict(x, d, _events=kev)[0]                    # noqa: E731
-        name, bytes_per_sample = "DiffDelGRU-HS[64] CHOWTAPE_WOWFLUTTER weights, D=1847", 16
-    else:
+        name, bytes_per_sample, fl = "DiffDelGRU-HS[64] CHOWTAPE_WOWFLUTTER weights, D=1847", 16, FLOP_PER_SAMPLE
+        kernel = "gru_mfma2_kernel"
+    elif workload == "tcn":
         model = ntm_amd.TCN().to(dev)
 
         def run():
             kev[0].record(); y = model(x); kev[1].record()
             return y
-        name, bytes_per_sample = "TCN 4x(k13, dil 1/10/100/1000, 32 ch) seeded weights", 8
-    # CPU leg of the side workloads (skipped with --no-cpu-baseline, like the headline's cpu_baseline): scattered
-    # streams against the oracle over the whole sequence -- the oracle is the checker here, never the thing measured
-    ref, rows = None, [r for r in (0, 17, B // 2 + 1, B - 1) if r < B]
-    if not a.no_cpu_baseline:
+        name, bytes_per_sample, fl = "TCN 4x(k13, dil 1/10/100/1000, 32 ch) seeded weights", 8, TCN_FLOP_PER_SAMPLE
+        kernel = "tcn_forward (first block + 3 MFMA blocks, output conv fused)"
+    else:
+        model = ntm_amd.harness.build_model(weights.W_GRU, device=dev)
+
+        def run():      # RNN.predict (code/model.py:218-246) unrolled so that the events bracket the main launch
+            model.initialize_hidden()
+            model.warm_start()
+            model.hidden = model.hidden.expand(1, B, 64).contiguous()
+            kev[0].record(); y = model.forward(x); kev[1].record()
+            return y
+        name, bytes_per_sample, fl = "GRU-HS[64] CHOWTAPE weights", 8, FLOP_PER_SAMPLE
+        kernel = "gru_mfma2_kernel" if B > 1024 else "gru_lat_kernel"
+    ref, rows = None, sorted({r for r in (0, 17, B // 2 + 1, B - 1) if 0 <= r < B})
+    if check:
         import oracle
         xs = x[rows, 0].cpu().numpy()
-        if a.workload == "diffdel":
-            w_or = oracle.Weights.from_state_dict({k: v.numpy() for k, v in weights.load_state_dict(weights.W_DIFFDEL).items()})
-            ref = oracle.diffdel_predict(w_or, xs, d[rows, 0].cpu().numpy(), model.max_delay)[0]
-        else:
+        sd = lambda nm: oracle.Weights.from_state_dict({k: v.numpy() for k, v in weights.load_state_dict(nm).items()})  # noqa: E731
+        if workload == "diffdel":
+            ref = oracle.diffdel_predict(sd(weights.W_DIFFDEL), xs, d[rows, 0].cpu().numpy(), model.max_delay, threads=threads)[0]
+        elif workload == "tcn":
             ref = oracle.tcn_forward(model.packed_params().cpu().numpy(), len(model.dilations), model.channels,
-                                     model.kernel_size, model.dilations, xs)
-    for _ in range(max(a.warmup, 1)):
+                                     model.kernel_size, model.dilations, xs, threads=threads)
+        else:
+            ref = oracle.gru_predict(sd(weights.W_GRU), xs, threads=threads)[0]
+    for _ in range(max(warmup, 1)):
         y0 = run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ms, k1, k2 = [], [], []
-    for _ in range(a.steps):
+    for _ in range(steps):
         ev0.record(); y = run(); ev1.record(); torch.cuda.synchronize()
         ms.append(ev0.elapsed_time(ev1))
         k1.append(kev[0].elapsed_time(kev[1]))
-        if a.workload == "diffdel":
+        if workload == "diffdel":
             k2.append(kev[1].elapsed_time(kev[2]))
     elapsed = time.perf_counter() - t0
     # dominant kernel: the GRU launch (DiffDelGRU: the delay line adds 3 flop/sample) resp. the TCN forward
-    # (43 520 FMA per sample; its five launches cannot be separated by events: profiles/ has the rocprofv3 split)
-    fl = FLOP_PER_SAMPLE if a.workload == "diffdel" else 2 * (13 * 32 + 32 + 3 * (32 * 13 * 32 + 32 * 32) + 32)
+    # (its five launches cannot be separated by events: profiles/ has the rocprofv3 split)
     ksec = float(np.mean(k1)) * 1e-3
     roof = {"bound": "mfma", "achieved": fl * B * T / ksec / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
             "frac": fl * B * T / ksec / 1e12 / PEAK_FP32_TFLOPS, "traffic": None, "flop_per_sample": fl,
-            "kernel": "gru_mfma2_kernel" if a.workload == "diffdel" else "tcn_forward (first block + 3 MFMA blocks, output conv fused)",
-            "kernel_ms": 1e3 * ksec}
-    if a.workload == "diffdel":
+            "kernel": kernel, "kernel_ms": 1e3 * ksec}
+    if workload == "diffdel":
         # K2 as a separate streaming pass: pre_d and d read once, y written once = 12 algorithmic bytes per sample
         # (the two gathered taps come from pre_d, i.e. from the same bytes); the carried buffer adds 8 D bytes per stream
         dsec = float(np.mean(k2)) * 1e-3
@@ -180,15 +202,55 @@ def side_workload(a):
                               "achieved": alg / dsec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                               "frac": alg / dsec / 1e9 / PEAK_HBM_GBS, "bytes_per_sample": 12,
                               "frac_at_16B_per_sample": 16.0 * B * T / dsec / 1e9 / PEAK_HBM_GBS}
+    res = {"workload": f"{name}, {B} segments x {T} samples fp32", "value": B * T * steps / elapsed, "unit": "samples/s",
+           "steps": steps, "warmup": max(warmup, 1), "ms_per_step": 1e3 * elapsed / steps,
+           "device_ms_per_step": float(np.mean(ms)), "bytes_per_sample": bytes_per_sample,
+           "kernel": kernel, "kernel_ms": 1e3 * ksec, "roofline": roof,
+           "checks": {"deterministic": bool(torch.equal(y, y0)), "streams_checked": rows if ref is not None else [],
+                      "samples_each": T, "tolerance": 1e-5,
+                      "vs_oracle_max_abs": None if ref is None else float(np.abs(y[rows, 0].cpu().numpy() - ref).max())}}
+    del x, y, y0, d, model
+    torch.cuda.empty_cache()
+    return res
+
+
+def side_workload(a):
+    """`--workload diffdel | tcn`: BASELINE configs[2] / configs[3] at the headline's batch as a line of their own
+    (single GPU, not the headline metric).  Like the headline line, the JSON carries the roofline of the dominant kernel
+    with its event-timed launch duration; for the DiffDelGRU step the HBM roofline of the delay-line pass sits beside it."""
+    assert torch.cuda.is_available()
+    r = measure_workload(a.workload, a.batch, a.samples, a.steps, a.warmup, not a.no_cpu_baseline, torch.device("cuda", 0),
+                         threads=_host_threads())
     print(json.dumps({
-        "metric": f"audio samples/sec (44.1 kHz) {a.workload}, batch={B}x{T}", "value": B * T * a.steps / elapsed,
-        "unit": "samples/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+        "metric": f"audio samples/sec (44.1 kHz) {a.workload}, batch={a.batch}x{a.samples}", "value": r["value"],
+        "unit": "samples/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": r["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{name}, {B} segments x {T} samples fp32"},
-        "device_ms_per_step": float(np.mean(ms)), "bytes_per_sample": bytes_per_sample,
-        "roofline": roof,
-        "checks": {"deterministic": bool(torch.equal(y, y0)), "streams_checked": rows if ref is not None else [],
-                   "vs_oracle_max_abs": None if ref is None else float(np.abs(y[rows, 0].cpu().numpy() - ref).max())}}))
+        "config": {"workload": r["workload"]}, "device_ms_per_step": r["device_ms_per_step"],
+        "bytes_per_sample": r["bytes_per_sample"], "roofline": r["roofline"], "checks": r["checks"]}))
+
+
+def _host_threads():
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return max(1, min(cores, 32))
+
+
+def other_workloads(a, dev, check):
+    """The BASELINE configs no other driver-run line covers, attached to the default line as `other_workloads` (never part
+    of `value`): configs[2] (DiffDelGRU) and configs[3] (TCN) at the headline's batch, and the GRU workload at the per-GPU
+    shapes of configs[4]'s strong-scaling legs (32 768 segments over 4 / 2 / 1 GPUs = 8192 / 16 384 / 32 768 per GPU)
+    -- PER-GPU LEGS measured on one GPU, not a scaling curve.  Each entry: whole-pass rate, the dominant kernel's
+    event-timed launch duration and roofline fraction, and scattered streams against the oracle."""
+    out = {"note": "single-GPU measurements beside the headline; gru_B* are the per-GPU shapes of configs[4]'s "
+                   "strong-scaling legs (per-GPU legs, not a scaling curve)"}
+    threads = _host_threads()
+    for wl in ("diffdel", "tcn"):
+        out[wl] = measure_workload(wl, a.batch, a.samples, a.other_steps, 1, check, dev, threads)
+    for b in a.other_gru_batches:
+        out[f"gru_B{b}"] = measure_workload("gru", b, a.samples, a.other_steps, 1, check, dev, threads)
+    return out
 
 
 def _free_port():
@@ -197,15 +259,38 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def spawn_ranks(n, argv):
+def _visible_gpus():
+    """Number of GPUs this job may use WITHOUT touching the HIP runtime in the launcher process: the visibility
+    variables first, else the KFD topology (GPU nodes carry a non-zero simd_count).  None = could not tell."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    top = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(top):
+            with open(os.path.join(top, node, "properties")) as f:
+                for line in f:
+                    if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                        n += 1
+        return n
+    except (OSError, ValueError):
+        return None
+
+
+def spawn_ranks(n, argv, grace=5.0):
     """`python bench.py --gpus N` without a launcher: start N fresh interpreters of this file, one per GPU, with
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, relay rank 0's stdout (the JSON line), and
-    return non-zero if any rank fails (the others are then terminated by PID so nobody waits in a collective).
-    This parent never initialises HIP (torch.cuda.device_count() does not), and no process that has is ever
-    re-exec'd: the children are new processes."""
+    return non-zero if any rank fails.  After the FIRST failure the other ranks get `grace` seconds to end by
+    themselves (a rank whose peer vanished usually dies of a signal inside the collective library), are then
+    terminated by PID, and EVERY status is reported; the rank blamed first is one that exited by itself with a
+    positive status (the culprit), in preference to ranks killed by a signal (its victims).
+    This parent never touches the HIP runtime or torch.cuda (the GPU count comes from the visibility variables or
+    the KFD topology), and no process that has is ever re-exec'd: the children are new processes."""
     backend = os.environ.get("NTM_DIST_BACKEND", "nccl")
-    have = torch.cuda.device_count()
-    if backend == "nccl" and have < n and "--launch-check" not in argv:
+    have = _visible_gpus()
+    if backend == "nccl" and have is not None and have < n and "--launch-check" not in argv:
         print(f"bench.py: --gpus {n} needs {n} visible GPUs for the RCCL run, found {have} "
               f"(NTM_DIST_BACKEND=gloo shares one GPU between ranks for a control-flow check)", file=sys.stderr)
         return 2
@@ -217,40 +302,44 @@ def spawn_ranks(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this driver
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
-    failed = None
-    out0 = ""
+    out0 = []
+    import threading
+    drain = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)   # rank 0's pipe never fills
+    drain.start()
+    status, order = {}, []                                       # rank -> exit status, in the order the exits were seen
+    deadline = None
     try:
-        live = set(range(n))
-        while live and failed is None:
-            for r in sorted(live):
-                rc = procs[r].poll() if r else None
-                if r == 0:
-                    try:                                       # drain rank 0's pipe while waiting for it
-                        out0_, _ = procs[0].communicate(timeout=0.2)
-                        out0 += out0_ or ""
-                        rc = procs[0].returncode
-                    except subprocess.TimeoutExpired:
-                        rc = None
-                if rc is not None:
-                    live.discard(r)
-                    if rc != 0:
-                        failed = (r, rc)
-                        break
-            if live and failed is None:
-                time.sleep(0.05)
+        while len(status) < n:
+            for r, p in enumerate(procs):
+                if r not in status and p.poll() is not None:
+                    status[r] = p.returncode
+                    order.append(r)
+                    if p.returncode != 0 and deadline is None:
+                        deadline = time.monotonic() + grace
+            if deadline is not None and time.monotonic() > deadline:
+                break
+            time.sleep(0.02)
     finally:
-        for p in procs:
-            if p.poll() is None:
-                p.terminate()
-        for p in procs:
+        terminated = [r for r, p in enumerate(procs) if p.poll() is None]
+        for r in terminated:
+            procs[r].terminate()
+        for r, p in enumerate(procs):
             try:
                 p.wait(timeout=20)
             except subprocess.TimeoutExpired:
                 p.kill()
-    sys.stdout.write(out0)
+                p.wait()
+        drain.join(timeout=10)
+    sys.stdout.write("".join(o or "" for o in out0))
     sys.stdout.flush()
-    if failed is not None:
-        print(f"bench.py: rank {failed[0]} exited with status {failed[1]}", file=sys.stderr)
+    failed = [r for r in order if status[r] != 0]
+    if failed:
+        culprits = [r for r in failed if status[r] > 0] or failed
+        first = culprits[0]
+        others = ", ".join(f"rank {r}: {status[r]}" for r in failed if r != first)
+        print(f"bench.py: rank {first} exited with status {status[first]}"
+              + (f" (then {others})" if others else "")
+              + (f"; terminated by the launcher: ranks {terminated}" if terminated else ""), file=sys.stderr)
         return 1
     return 0
 
@@ -264,9 +353,13 @@ def launch_check(a):
     total = a.total_batch if a.scaling == "strong" else a.batch * world
     lo, hi = D.shard_range(total, rank, world) if a.scaling == "strong" else (rank * a.batch, (rank + 1) * a.batch)
     v = torch.tensor([float(hi - lo), float(rank), 1.0], dtype=torch.float64)
+    if a.fail_rank == rank and a.fail_early:
+        os._exit(3)                 # a rank that dies BEFORE the collective: its peers are left inside the all-reduce
     if world > 1:
         torch.distributed.all_reduce(v)
     D.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()       # before any rank leaves: no peer dies inside gloo's teardown
     if rank == 0:
         print(json.dumps({"launch_check": True, "world": world, "segments_total": int(v[0]), "rank_sum": int(v[1]),
                           "ranks": int(v[2]), "scaling": a.scaling}))
@@ -287,10 +380,16 @@ def main():
     ap.add_argument("--variant", default="auto", choices=["auto", "mfma2", "mfma4", "mfma", "valu", "f16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the opt-in f16x3 kernel leg")
+    ap.add_argument("--other", default="auto", choices=["auto", "on", "off"],
+                    help="attach `other_workloads` (configs[2], [3] and the per-GPU shapes of configs[4]) to the line: "
+                         "auto = only for the default single-GPU workload (4096 x 65536)")
+    ap.add_argument("--other-steps", type=int, default=3)
+    ap.add_argument("--other-gru-batches", type=lambda v: [int(t) for t in v.split(",") if t], default=[8192, 16384, 32768])
     ap.add_argument("--workload", default="gru", choices=["gru", "diffdel", "tcn"],
                     help="gru = BASELINE configs[1] (the headline metric); diffdel = configs[2]; tcn = configs[3]")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--fail-early", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
 
     # N > 1 and nobody gave us a rank: this process becomes the launcher (before anything touches the GPU)
@@ -379,6 +478,9 @@ def main():
             target = y.clone()
     if target is None:                      # --warmup 0: still need the determinism target
         target = one_pass(None)[0].clone()
+    if a.fail_rank == rank:                 # test hook: a rank that dies after warm-up, its peers left in the barrier
+        torch.cuda.synchronize()
+        os._exit(3)
 
     step_evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     D.barrier()
@@ -512,6 +614,12 @@ def main():
         yo, _ = oracle.gru_predict(w_or, x[rows, 0].cpu().numpy(), threads=out["cpu_baseline"]["cores"])
         out["checks"]["streams_vs_oracle"] = {"rows": rows, "samples_each": T,
                                               "max_abs": float(np.abs(y[rows, 0].cpu().numpy() - yo).max()), "tolerance": 1e-5}
+    # ---- the BASELINE configs no other driver-run line covers (configs[2], [3], the per-GPU shapes of configs[4]); after
+    #      the headline's timed region and CPU leg, which they leave untouched; never part of `value`
+    if world == 1 and (a.other == "on" or (a.other == "auto" and (B, T) == (4096, 65536) and a.variant in ("auto", "mfma2"))):
+        del x, y, target
+        torch.cuda.empty_cache()
+        out["other_workloads"] = other_workloads(a, dev, check=not a.no_cpu_baseline)
     print(json.dumps(out))
 
 

@@ -79,11 +79,19 @@ def lib():
             raise NtmError(f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
                            "(there is no CPU fallback for this path)")
         handle = ctypes.CDLL(LIB_PATH)
+        # the version first: a stale library (the .so files are build artefacts) lacks newer symbols, and the helpful
+        # message must come before the bare AttributeError of a missing one
+        try:
+            ver = handle.ntm_abi_version
+        except AttributeError:
+            raise NtmError(f"{LIB_PATH} does not export ntm_abi_version: not a libntm.so of this tree, rebuild it") from None
+        ver.restype, ver.argtypes = _SIGNATURES["ntm_abi_version"]
+        if ver() != ABI_VERSION:
+            raise NtmError(f"{LIB_PATH} has ABI version {ver()}, this binding needs {ABI_VERSION}: rebuild it "
+                           f"(`make -C {os.path.join(_HERE, 'csrc')}`)")
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype, fn.argtypes = res, args
-        if handle.ntm_abi_version() != ABI_VERSION:
-            raise NtmError(f"{LIB_PATH} has ABI version {handle.ntm_abi_version()}, this binding needs {ABI_VERSION}: rebuild it")
         _lib = handle
     return _lib
 

@@ -359,32 +359,34 @@ class SegmentFeeder:
             model.warm_start()
             if B != 1:
                 model.hidden = model.hidden.expand(1, B, model.hidden_size).contiguous()
-        bounds = [(c0, min(L, c0 + chunk)) for c0 in range(0, L, chunk)]
-        ev = send(*bounds[0])
-        back = torch.cuda.Stream(device=device) if out_host is not None else None
-        if out_host is not None:
-            assert tuple(out_host.shape) == (B, 1, L) and out_host.dtype == torch.float32 and out_host.is_contiguous()
-        for i, (c0, c1) in enumerate(bounds):
-            nxt = send(*bounds[i + 1]) if i + 1 < len(bounds) else None
-            cur.wait_event(ev)
-            if is_dd:    # GRU + delay line on the chunk (state of both carried); trajectory seconds -> samples
-                y[:, :, c0:c1] = model.forward(x[:, :, c0:c1], dtr[:, :, c0:c1] * float(self.fs))[0]
-            else:
-                model.forward_into(x[:, 0, c0:c1], y[:, 0, c0:c1])
+        try:     # the deferred-check mode of the delay line is restored whatever the chunk loop does
+            bounds = [(c0, min(L, c0 + chunk)) for c0 in range(0, L, chunk)]
+            ev = send(*bounds[0])
+            back = torch.cuda.Stream(device=device) if out_host is not None else None
+            if out_host is not None:
+                assert tuple(out_host.shape) == (B, 1, L) and out_host.dtype == torch.float32 and out_host.is_contiguous()
+            for i, (c0, c1) in enumerate(bounds):
+                nxt = send(*bounds[i + 1]) if i + 1 < len(bounds) else None
+                cur.wait_event(ev)
+                if is_dd:    # GRU + delay line on the chunk (state of both carried); trajectory seconds -> samples
+                    y[:, :, c0:c1] = model.forward(x[:, :, c0:c1], dtr[:, :, c0:c1] * float(self.fs))[0]
+                else:
+                    model.forward_into(x[:, 0, c0:c1], y[:, 0, c0:c1])
+                if back is not None:
+                    done = torch.cuda.Event()
+                    done.record(cur)
+                    back.wait_event(done)
+                    rc = lib.ntm_copy2d_async(out_host[0, 0, c0:].data_ptr(), 4 * L, y[0, 0, c0:].data_ptr(), 4 * L,
+                                              4 * (c1 - c0), B, 1, back.cuda_stream)
+                    _lib.check(rc, "ntm_copy2d_async")
+                ev = nxt
             if back is not None:
-                done = torch.cuda.Event()
-                done.record(cur)
-                back.wait_event(done)
-                rc = lib.ntm_copy2d_async(out_host[0, 0, c0:].data_ptr(), 4 * L, y[0, 0, c0:].data_ptr(), 4 * L,
-                                          4 * (c1 - c0), B, 1, back.cuda_stream)
-                _lib.check(rc, "ntm_copy2d_async")
-            ev = nxt
-        if back is not None:
-            cur.wait_stream(back)                               # a sync of the caller's stream covers the copies back
-        if is_dd:
-            model.diffdel.defer_check = deferred
-            if not deferred:
-                model.diffdel.raise_if_violated()              # the assert of code/model.py:284, once for all chunks
+                cur.wait_stream(back)                               # a sync of the caller's stream covers the copies back
+        finally:
+            if is_dd:
+                model.diffdel.defer_check = deferred
+        if is_dd and not deferred:
+            model.diffdel.raise_if_violated()                  # the assert of code/model.py:284, once for all chunks
         for a in (x, t, dtr):
             if a is not None:
                 a.record_stream(side)

@@ -12,7 +12,15 @@ Deliberate differences from the reference (documented in DESIGN.md):
     (the reference raises for B>1).
   * predict() runs the whole sequence in one persistent launch; `segment_length=2048` reproduces
     the reference's chunk loop (same result, state is carried either way).
-  * Training entry points (train_epoch / validate / detach_*) are out of scope.
+  * validate() (code/model.py:163-216, :513-616 -- the reference's own batched, inference-only use of forward,
+    called by code/train.py:242) and detach_hidden / detach_buffer are here; train_epoch (backward) is out of
+    scope.
+  * warm_start() from a fresh state is a pure function of the parameters: its result (hidden state; for the
+    DiffDelGRU also the delay buffer) is computed by the kernel ONCE per (parameter version, device, kernel variant,
+    delay-line length) and kept, so a predict() is one launch instead of two.  Same numbers as recomputing it
+    (code/model.py:58-65, :382-391 recompute it every time); `warm_cache = False` turns the cache off,
+    `invalidate_warm_cache()` drops it (needed only after writing parameters through `.data`, which by-passes
+    torch's version counters).
 """
 import numpy as np
 import torch
@@ -71,6 +79,18 @@ class _GRUHead(torch.nn.Module):
     # product kernels (libntm.so): "auto" | "mfma2" | "lat" | "f16x3" (opt-in);  laboratory kernels for A/B and as
     # independent implementations in the tests (libntm_lab.so): "mfma" | "valu" | "mfma3" | "mfma4"  (NTM_GRU_*)
     kernel_variant = "auto"
+    warm_cache = True          # keep the warm-start state per parameter version (see the module docstring)
+
+    def _warm_key(self, *extra):
+        """Identity of everything warm_start() depends on: the parameter tensors (storage + torch version counter,
+        bumped by load_state_dict / any in-place update; .to(device) replaces the storage), kernel variant, sizes."""
+        ps = [self.GRU.weight_ih_l0, self.GRU.weight_hh_l0, self.GRU.bias_ih_l0, self.GRU.bias_hh_l0,
+              self.output.weight, self.output.bias]
+        return (tuple((p.data_ptr(), p._version, str(p.device)) for p in ps if p is not None), self.kernel_variant,
+                self.hidden_size, bool(self.skip)) + extra
+
+    def invalidate_warm_cache(self):
+        self._warm = None
 
     def _init_net(self, input_size, hidden_size, output_size, skip, head_bias):
         if input_size != 1 or output_size != 1:
@@ -84,6 +104,7 @@ class _GRUHead(torch.nn.Module):
         self.GRU = _GRUParams(input_size, hidden_size)
         self.output = _LinearParams(hidden_size, output_size, bias=head_bias)
         self.hidden = None
+        self._warm = None          # (key, state tensors) of the last warm_start() from a fresh state
 
     def _hidden_for(self, B, device):
         H = self.hidden_size
@@ -145,11 +166,24 @@ class RNN(_GRUHead):
         self.hidden = None
 
     def warm_start(self):
-        """Process 1024 samples of silence, B=1 (code/model.py:58-65)."""
+        """Process 1024 samples of silence, B=1 (code/model.py:58-65).  From a fresh state (hidden None) the result
+        depends on the parameters only and is kept per parameter version (module docstring)."""
         START_LEN = 2**10
+        fresh = self.hidden is None and self.warm_cache
+        if fresh:
+            key = self._warm_key()
+            if self._warm is not None and self._warm[0] == key:
+                self.hidden = self._warm[1].clone()
+                return
         with torch.no_grad():
             x = torch.zeros((1, 1, START_LEN), device=self.GRU.weight_hh_l0.device)
             _ = self(x)
+        if fresh:
+            self._warm = (key, self.hidden.clone())
+
+    def detach_hidden(self):
+        """Detach the hidden state from the computational graph (code/model.py:54-56): a clone here, there is no graph."""
+        self.hidden = self.hidden.clone().detach()
 
     @torch.no_grad()
     def forward(self, x):
@@ -176,6 +210,35 @@ class RNN(_GRUHead):
             output[:, :, sl] = self.forward(input[:, :, sl])
         return output
 
+    @torch.no_grad()
+    def validate(self, dataloader, loss_fcn, store_examples=True):
+        """Loss over a validation set (code/model.py:163-216; called by code/train.py:242): per batch the hidden state
+        is aggregated on the first 1024 REAL samples, the rest is predicted in one launch and scored with
+        `loss_fcn(pred, target)`; returns (mean loss over batches, examples).  `dataloader`: anything with len() that
+        yields (input, target, meta) batches of shape (B, C, T); only channel 0 is used, as in the reference."""
+        INIT_LEN = 2**10
+        device = self.GRU.weight_hh_l0.device
+        self.eval()
+        num_batches = len(dataloader)
+        val_loss = 0
+        examples = []
+        for _, batch in enumerate(dataloader):
+            input, target, _ = batch
+            if input.shape[1] > 1:            # only the audio channel counts for the loss
+                input, target = input[:, :1, :], target[:, :1, :]
+            input, target = input.to(device), target.to(device)
+            self.initialize_hidden()
+            _ = self.forward(input[:, :, :INIT_LEN])
+            input = input[:, :, INIT_LEN:]
+            target = target[:, :, INIT_LEN:]
+            pred = self.forward(input)
+            loss = loss_fcn(pred, target)
+            val_loss += loss.item() if hasattr(loss, "item") else float(loss)
+            if store_examples:
+                examples.append({"input": input[0, 0, :], "target": target[0, 0, :], "prediction": pred[0, 0, :]})
+        val_loss /= num_batches
+        return val_loss, examples
+
 
 class TimeVaryingDelayLine(torch.nn.Module):
     """Time-varying feed-forward delay line, linear interpolation (reference: code/model.py:249-332).
@@ -197,19 +260,31 @@ class TimeVaryingDelayLine(torch.nn.Module):
         # like the reference, batch 2 until init_buffer() is called (code/model.py:267)
         self.buffer = torch.zeros(2, channels, max_delay)
         self._err = None
+        self._unchecked = False      # deferred launches since the flag was last looked at
+        self._fresh = False
         self.defer_check = False
 
     def init_buffer(self, N, max_d):
         """Zero buffer for mini-batch size N; overwrites max_delay (code/model.py:326-332)."""
         device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        if self._unchecked:
+            # deferred forward() calls whose range check nobody has looked at yet: a violation among them must not
+            # vanish with the state it froze -- the reference would have raised at that call (code/model.py:284)
+            self.raise_if_violated()
         self.max_delay = max_d
         self.buffer = torch.zeros(N, 1, self.max_delay).to(device)
+        self._fresh = True           # all zeros, untouched since (DiffDelRNN.warm_start's cache looks at it)
         if self._err is not None:
             self._err.zero_()
+
+    def detach_buffer(self):
+        """Detach the buffer from the computational graph (code/model.py:322-324): a clone here."""
+        self.buffer = self.buffer.clone().detach()
 
     def raise_if_violated(self):
         """The reference's `assert self.max_delay >= torch.max(dt)` for every forward() since the last check
         (one host synchronisation).  The buffer holds the state before the first violating call."""
+        self._unchecked = False
         if self._err is not None and int(self._err.item()) != 0:
             self._err.zero_()
             raise AssertionError("max_delay >= max(dt) violated")
@@ -225,11 +300,14 @@ class TimeVaryingDelayLine(torch.nn.Module):
         if self._err is None or self._err.device != xbt.device:
             self._err = torch.zeros(1, device=xbt.device, dtype=torch.int32)
         y = torch.empty_like(xbt)
+        self._fresh = False
         rc = _lib.lib().ntm_delay_forward(ptr(xbt), ptr(dbt), ptr(y), B, T, ptr(self.buffer), D, int(bool(warmup)),
                                           ptr(self._err), _lib.current_stream())
         _lib.check(rc, "ntm_delay_forward")
         if not self.defer_check:
             self.raise_if_violated()
+        else:
+            self._unchecked = True
         return y
 
     @torch.no_grad()
@@ -258,13 +336,32 @@ class DiffDelRNN(_GRUHead):
         self.diffdel.init_buffer(N, int(max_D) + 1)
 
     def warm_start(self):
-        """1024 samples of silence with zero delay, B=1 (code/model.py:382-391)."""
+        """1024 samples of silence with zero delay, B=1 (code/model.py:382-391).  From a fresh state (hidden None,
+        zero buffer of batch 1) the result -- hidden state and delay buffer -- depends on the parameters and the
+        delay-line length only and is kept per parameter version (module docstring)."""
         START_LEN = 2**10
         dev = self.GRU.weight_hh_l0.device
+        dl = self.diffdel
+        fresh = (self.warm_cache and self.hidden is None and dl._fresh and dl.buffer.shape[0] == 1
+                 and dl.buffer.device == dev)
+        if fresh:
+            key = self._warm_key(int(dl.max_delay))
+            if self._warm is not None and self._warm[0] == key:
+                self.hidden = self._warm[1].clone()
+                dl.buffer = self._warm[2].clone()
+                dl._fresh = False
+                return
         with torch.no_grad():
             x = torch.zeros((1, 1, START_LEN), device=dev)
             d_traj = torch.zeros((1, 1, START_LEN), device=dev)
             _, __ = self(x, d_traj)
+        if fresh:
+            self._warm = (key, self.hidden.clone(), dl.buffer.clone())
+
+    def detach_hidden(self):
+        """Detach hidden state and delay buffer from the computational graph (code/model.py:377-380): clones here."""
+        self.hidden = self.hidden.clone().detach()
+        self.diffdel.detach_buffer()
 
     @torch.no_grad()
     def forward(self, x, del_traj, warmup=False, _events=None):
@@ -313,6 +410,51 @@ class DiffDelRNN(_GRUHead):
         if not deferred:
             self.diffdel.raise_if_violated()
         return output, output_pre_d
+
+    @torch.no_grad()
+    def validate(self, dataloader, loss_fcn, store_examples=True):
+        """Loss over a validation set (code/model.py:513-616): INIT_LEN = nextpow2(int(analyser max_delay * fs)); per
+        batch the state is aggregated on the first INIT_LEN real samples (`warmup=True`: the delay line only fills its
+        buffer), then the rest is predicted and `loss_fcn` is evaluated on 2048-sample pieces whose mean is the batch's
+        loss -- the reference forwards those pieces one by one; here they come out of ONE launch (chunked == one-shot
+        bit for bit, state carried either way) and only the loss loop runs per piece.  Needs of the dataloader what the
+        reference needs: len(), (input, target, meta) batches with meta['delay_trajectory'] (B, T) in seconds,
+        `.dataset.delay_analyzer.max_delay` (seconds) and `.dataset.fs`."""
+        from .utilities import nextpow2
+        fs = dataloader.dataset.fs
+        INIT_LEN = nextpow2(int(dataloader.dataset.delay_analyzer.max_delay * fs))
+        TBPTT_LEN = 2**11
+        device = self.GRU.weight_hh_l0.device
+        self.eval()
+        num_batches = len(dataloader)
+        val_loss = 0
+        examples = []
+        for _, batch in enumerate(dataloader):
+            input, target, meta = batch
+            if input.shape[1] > 1:
+                input, target = input[:, :1, :], target[:, :1, :]
+            d_traj = meta["delay_trajectory"].float()
+            d_traj = d_traj.unsqueeze(1) * fs
+            input, target, d_traj = input.to(device), target.to(device), d_traj.to(device)
+            num_minibatches = int(np.ceil((input.shape[-1] - INIT_LEN) / TBPTT_LEN))
+            self.initialize_hidden(input.shape[0], self.max_delay)
+            _, __ = self.forward(input[:, :, :INIT_LEN], d_traj[:, :, :INIT_LEN], warmup=True)
+            pred = torch.empty(target.shape, device=device, dtype=torch.float32)
+            pre_d = torch.empty(target.shape, device=device, dtype=torch.float32)
+            if num_minibatches > 0:
+                pred[:, :, INIT_LEN:], pre_d[:, :, INIT_LEN:] = self.forward(input[:, :, INIT_LEN:], d_traj[:, :, INIT_LEN:])
+            minibatch_loss = 0
+            for k in range(num_minibatches):
+                sl = slice(INIT_LEN + k * TBPTT_LEN, INIT_LEN + (k + 1) * TBPTT_LEN)
+                loss = loss_fcn(pred[:, :, sl], target[:, :, sl])
+                minibatch_loss += loss.item() if hasattr(loss, "item") else float(loss)
+            minibatch_loss /= num_minibatches           # ZeroDivisionError for T <= INIT_LEN, as in the reference
+            val_loss += minibatch_loss
+            if store_examples:
+                examples.append({"input": input[0, 0, INIT_LEN:], "target": target[0, 0, INIT_LEN:],
+                                 "prediction": pred[0, 0, INIT_LEN:], "prediction_pre_d": pre_d[0, 0, INIT_LEN:]})
+        val_loss /= num_batches
+        return val_loss, examples
 
 
 # ------------------------------------------------------------------------------------------

@@ -25,3 +25,20 @@ def oracle_weights(name):
 
 def load(npz):
     return np.load(os.path.join(GOLDEN, npz), allow_pickle=False)
+
+
+def validate_batches(seed, n_batches, b, t, fs):
+    """The synthetic validation set of golden g18 (tools/make_goldens_validate.py), regenerated from its seed:
+    [(input (b,2,t), target (b,2,t), delay trajectory (b,t) in seconds)] -- two channels like the dataset's stereo items
+    (audio + pilot), so that the `[:, :1, :]` cut of validate() is exercised."""
+    rng = np.random.default_rng(seed)
+    out = []
+    n = np.arange(t)
+    for _ in range(n_batches):
+        x = rng.uniform(-0.5, 0.5, (b, 2, t)).astype(np.float32)
+        tgt = (0.7 * np.tanh(1.5 * x) + 0.01 * rng.standard_normal((b, 2, t))).astype(np.float32)
+        f = rng.uniform(0.5, 3.0, (b, 1))
+        ph = rng.uniform(0, 2 * np.pi, (b, 1))
+        d = (100.0 + 45.0 * np.sin(2 * np.pi * f * n / fs * 40 + ph) + 5.0 * rng.uniform(-1, 1, (b, 1))) / fs
+        out.append((x, tgt, d))
+    return out

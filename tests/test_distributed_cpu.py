@@ -108,6 +108,18 @@ def test_bench_launcher_propagates_a_failing_rank():
     assert r.returncode != 0 and "rank 1 exited with status 3" in r.stderr
 
 
+def test_bench_launcher_blames_the_culprit_not_its_victims():
+    """A rank that dies BEFORE the collective leaves its peers inside the all-reduce, where they abort (signal) or
+    raise (status 1) or hang until the launcher terminates them: whatever they do, the launcher names the rank that
+    exited by itself with a positive status first, lists the others, and returns non-zero well inside the timeout."""
+    import time
+    t0 = time.monotonic()
+    r, lines = _run_bench(["--gpus", "4", "--launch-check", "--fail-rank", "2", "--fail-early"])
+    assert r.returncode != 0 and "rank 2 exited with status 3" in r.stderr, r.stderr[-1500:]
+    assert time.monotonic() - t0 < 120
+    assert not lines                                      # nobody printed a result line
+
+
 def test_bench_under_an_external_launcher_keeps_working():
     """RANK / WORLD_SIZE given by a launcher (torch.distributed.run style): bench.py must NOT spawn again."""
     import subprocess

@@ -1,0 +1,366 @@
+"""GPU parity, round 3: the reference's own validate() methods (golden g18), the cached warm-start state, the
+`ntm_diffdel_gru_forward` entry point called through raw ctypes and from the torch-free C++ caller, eight ranks sharing
+this box's GPU over gloo, and the `other_workloads` of the default bench line.  Tolerance for the GRU path: 1e-5 abs
+fp32 (BASELINE.json north_star); the delay line is bit-exact on the pre-delay signal it is given."""
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import ROOT, load, oracle_weights, validate_batches
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+W_G = "GRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE]_BEST"
+W_G_ESR = "GRU-HS[64]-L[ESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE]_BEST"
+W_D = "DiffDelGRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE_WOWFLUTTER]_BEST"
+
+
+@pytest.fixture(scope="module")
+def ntm():
+    import ntm_amd
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    ntm_amd._lib.lib()       # raises if libntm.so is missing: no silent fallback
+    return ntm_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def p(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+# ----------------------------------------------------------------------------- validate() (golden g18)
+class _Loader:
+    """What RNN.validate / DiffDelRNN.validate use of a dataloader (tools/make_goldens_validate.py builds the same)."""
+
+    def __init__(self, batches, with_meta, max_delay_s, fs):
+        self.batches, self.with_meta = batches, with_meta
+        self.dataset = types.SimpleNamespace(delay_analyzer=types.SimpleNamespace(max_delay=max_delay_s), fs=fs)
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        for x, t, d in self.batches:
+            yield torch.from_numpy(x), torch.from_numpy(t), ({"delay_trajectory": torch.from_numpy(d)} if self.with_meta else {})
+
+
+def _esr(pred, target):
+    return ((target - pred) ** 2).mean() / ((target ** 2).mean() + 1e-5)
+
+
+def test_g18_validate_matches_the_reference(ntm):
+    """`val_loss, examples = model.validate(dataloader_val, loss_fcn)` (code/train.py:242) against what the reference's
+    own methods returned on the same batches (code/model.py:163-216, :513-616): loss, the examples' predictions, the
+    carried state; host-CPU batches go to the model's device as in the reference."""
+    g = load("g18_validate.npz")
+    fs = int(g["fs"])
+    batches = validate_batches(int(g["seed"]), int(g["n_batches"]), int(g["B"]), int(g["T"]), fs)
+    m = ntm.harness.build_model(W_G)
+    val, ex = m.validate(_Loader(batches, False, float(g["max_delay_s"]), fs), _esr)
+    assert abs(val - float(g["rnn_val_loss"])) < 1e-5 and len(ex) == len(batches)
+    for k, e in enumerate(ex):
+        assert set(e) == {"input", "target", "prediction"}
+        assert np.abs(e["prediction"].cpu().numpy() - g["rnn_pred"][k]).max() < TOL
+        assert np.array_equal(e["input"].cpu().numpy(), batches[k][0][0, 0, 1024:])
+        assert np.array_equal(e["target"].cpu().numpy(), batches[k][1][0, 0, 1024:])
+    assert np.abs(m.hidden.cpu().numpy() - g["rnn_hidden"]).max() < TOL
+    val2, ex2 = m.validate(_Loader(batches, False, float(g["max_delay_s"]), fs), _esr, store_examples=False)
+    assert val2 == val and ex2 == []
+
+    md = ntm.DiffDelRNN(1, 64, 1, max_delay=int(g["model_max_delay"]))
+    md.load_state_dict(ntm.weights.load_state_dict(W_D))
+    md = md.to("cuda").eval()
+    val, ex = md.validate(_Loader(batches, True, float(g["max_delay_s"]), fs), _esr)
+    assert abs(val - float(g["dd_val_loss"])) < 1e-5
+    for k, e in enumerate(ex):
+        assert set(e) == {"input", "target", "prediction", "prediction_pre_d"}
+        assert np.abs(e["prediction_pre_d"].cpu().numpy() - g["dd_pre_d"][k]).max() < TOL
+        assert np.abs(e["prediction"].cpu().numpy() - g["dd_pred"][k]).max() < TOL
+    assert np.abs(md.hidden.cpu().numpy() - g["dd_hidden"]).max() < TOL
+    assert np.abs(md.diffdel.buffer.cpu().numpy() - g["dd_buffer"]).max() < TOL
+    # detach_hidden / detach_buffer (code/model.py:54-56, :322-324, :377-380): new tensors, same values
+    h0, b0 = md.hidden, md.diffdel.buffer
+    md.detach_hidden()
+    assert md.hidden is not h0 and torch.equal(md.hidden, h0) and md.hidden.data_ptr() != h0.data_ptr()
+    assert md.diffdel.buffer is not b0 and torch.equal(md.diffdel.buffer, b0)
+    h0 = m.hidden
+    m.detach_hidden()
+    assert m.hidden is not h0 and torch.equal(m.hidden, h0)
+
+
+# ----------------------------------------------------------------------------- cached warm-start state
+def test_warm_start_cache_is_bit_identical_and_follows_the_parameters(ntm):
+    """warm_start() from a fresh state is computed once per parameter version: a second predict() launches nothing for
+    it and returns the same bits as a model that recomputes it (warm_cache = False); load_state_dict, a kernel-variant
+    change and a different delay-line length each invalidate; goldens g1 / g3 still hold."""
+    g1, g3 = load("g1_predict_16x8192.npz"), load("g3_warm_start.npz")
+    x = dev(g1["x"][:3].reshape(3, 1, -1))
+    cached, plain = ntm.harness.build_model(W_G), ntm.harness.build_model(W_G)
+    plain.warm_cache = False
+    ya = cached.predict(x)
+    assert cached._warm is not None and plain._warm is None
+    key = cached._warm[0]
+    yb, yc = cached.predict(x), plain.predict(x)
+    assert plain._warm is None and cached._warm[0] == key
+    assert torch.equal(ya, yb) and torch.equal(ya, yc)
+    cached.initialize_hidden(); cached.warm_start()
+    assert np.abs(cached.hidden.cpu().numpy() - g3["wg_hidden"]).max() < 2e-6
+    # the cached tensor is never handed out itself: mutating the model's state does not poison the cache
+    cached.hidden.zero_()
+    cached.initialize_hidden(); cached.warm_start()
+    assert np.abs(cached.hidden.cpu().numpy() - g3["wg_hidden"]).max() < 2e-6
+    # warm_start() continuing from an existing state (code/model.py:58-65 continues from self.hidden) is computed, not served
+    cached.hidden = torch.full((1, 1, 64), 0.5, device="cuda")
+    cached.warm_start()
+    plain.hidden = torch.full((1, 1, 64), 0.5, device="cuda")
+    plain.warm_start()
+    assert torch.equal(cached.hidden, plain.hidden) and cached._warm[0] == key
+    # new parameters -> recomputed
+    cached.load_state_dict(ntm.weights.load_state_dict(W_G_ESR))
+    cached.initialize_hidden(); cached.warm_start()
+    assert cached._warm[0] != key and np.abs(cached.hidden.cpu().numpy() - g3["wg_esr_hidden"]).max() < 2e-6
+    other = ntm.harness.build_model(W_G_ESR)
+    other.warm_cache = False
+    assert torch.equal(cached.predict(x), other.predict(x))
+    # in-place parameter update (what an optimiser step does) -> recomputed
+    k2 = cached._warm[0]
+    with torch.no_grad():
+        cached.output.bias.add_(0.25)
+    y_shift = cached.predict(x)
+    assert cached._warm[0] != k2 and torch.allclose(y_shift, other.predict(x) + 0.25, atol=1e-6)
+    # kernel variant is part of the key (the variants differ in the last bits)
+    k3 = cached._warm[0]
+    cached.kernel_variant = "mfma2"
+    cached.predict(x)
+    assert cached._warm[0] != k3
+
+    # DiffDelGRU: hidden AND delay buffer are cached, keyed by the delay-line length too
+    md = ntm.DiffDelRNN(1, 64, 1, max_delay=300)
+    md.load_state_dict(ntm.weights.load_state_dict(W_D))
+    md = md.to("cuda").eval()
+    rng = np.random.default_rng(3)
+    xd = dev(rng.uniform(-0.5, 0.5, (2, 1, 3000)).astype(np.float32))
+    dd = dev((150 + 100 * np.sin(np.arange(3000) / 200.0))[None, None, :].repeat(2, 0).astype(np.float32))
+    y1, p1 = md.predict(xd, dd)
+    kd = md._warm[0]
+    y2, p2 = md.predict(xd, dd)
+    assert md._warm[0] == kd and torch.equal(y1, y2) and torch.equal(p1, p2)
+    md.initialize_hidden(1, 300); md.warm_start()
+    assert np.abs(md.hidden.cpu().numpy() - g3["wd_hidden"]).max() < 2e-6
+    assert np.abs(md.diffdel.buffer.cpu().numpy() - g3["wd_buffer"]).max() < 2e-6
+    md.warm_cache = False
+    y3, p3 = md.predict(xd, dd)
+    assert torch.equal(y1, y3) and torch.equal(p1, p3)
+    md.warm_cache = True
+    md.initialize_hidden(1, 200); md.warm_start()                     # another delay-line length: another state
+    assert md._warm[0] != kd and md.diffdel.buffer.shape[-1] == 201
+    # a buffer that is not fresh (batch of 2, or already used) is never served from the cache
+    md.initialize_hidden(2, 300)
+    with pytest.raises(RuntimeError):
+        md.warm_start()                                               # B = 1 input against a batch-2 buffer, as in the reference
+
+
+# ----------------------------------------------------------------------------- ntm_diffdel_gru_forward through raw ctypes
+def _dd_call(L, w, x, d, y, pre, h, buf, D, flag, warmup=0):
+    B, T = x.shape
+    return L.ntm_diffdel_gru_forward(p(w["GRU.weight_ih_l0"]), p(w["GRU.weight_hh_l0"]), p(w["GRU.bias_ih_l0"]),
+                                     p(w["GRU.bias_hh_l0"]), p(w["output.weight"]), 64, p(x), p(d), p(y), p(pre), B, T,
+                                     p(h), p(buf), D, warmup, p(flag), None)
+
+
+def test_diffdel_entry_point_raw_ctypes(ntm):
+    """include/ntm.h `ntm_diffdel_gru_forward` (replaces DiffDelRNN.forward, code/model.py:393-424) called directly:
+    golden g5 (the reference's predict = warm-up call + forward), the oracle on a ragged batch, chunked == one-shot,
+    warm-up mode, the refusal of pre_d == y, and a delay beyond D (sticky flag, dl_state untouched, later calls no-ops
+    for the delay line until the flag is cleared)."""
+    L = ntm._lib.lib()
+    w = {k: v.cuda() for k, v in ntm.weights.load_state_dict(W_D).items()}
+    g = load("g5_diffdel_predict.npz")
+    D = int(g["D_effective"])
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    # g5 = predict: warm-up (1024 zeros, zero delay, B = 1) then the sequence, state carried through h / buf
+    h, buf = torch.zeros(1, 64, device="cuda"), torch.zeros(1, D, device="cuda")
+    z = torch.zeros(1, 1024, device="cuda")
+    yz, pz = torch.empty_like(z), torch.empty_like(z)
+    assert _dd_call(L, w, z, z, yz, pz, h, buf, D, flag) == 0
+    x, d = dev(g["x"][0]), dev(g["d"][0])
+    y, pre = torch.empty_like(x), torch.empty_like(x)
+    assert _dd_call(L, w, x, d, y, pre, h, buf, D, flag) == 0
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    assert np.abs(pre.cpu().numpy() - g["pre_d"][0]).max() < TOL and np.abs(y.cpu().numpy() - g["y"][0]).max() < TOL
+    assert np.abs(h.cpu().numpy() - g["hidden"][0]).max() < TOL and np.abs(buf.cpu().numpy() - g["buffer"][0]).max() < TOL
+    # the same pre_d through the oracle's delay line: y bit for bit (the delay line is exact)
+    yo, bo = oracle.delay_forward(pre.cpu().numpy(), g["d"][0], pz[:, -D:].cpu().numpy() if D <= 1024 else
+                                  np.concatenate([np.zeros((1, D - 1024), np.float32), pz.cpu().numpy()], 1))
+    assert np.array_equal(y.cpu().numpy(), yo) and np.array_equal(buf.cpu().numpy(), bo)
+
+    # ragged batch against the oracle, one-shot and in three chunks (T not a multiple of anything, T < D in a chunk)
+    rng = np.random.default_rng(11)
+    B, T, D2 = 37, 2500, 301
+    xs = rng.uniform(-0.5, 0.5, (B, T)).astype(np.float32)
+    ds = np.clip(150 + 140 * np.sin(np.arange(T)[None, :] / rng.uniform(50, 400, (B, 1))) + rng.uniform(-5, 5, (B, 1)), 0, D2).astype(np.float32)
+    h0 = rng.uniform(-0.3, 0.3, (B, 64)).astype(np.float32)
+    b0 = rng.uniform(-0.3, 0.3, (B, D2)).astype(np.float32)
+    wo = oracle_weights(W_D)
+    yo, po, ho, bo = oracle.diffdel_forward(wo, xs, ds, h0, b0)
+    h, buf = dev(h0), dev(b0)
+    x, d = dev(xs), dev(ds)
+    y, pre = torch.empty_like(x), torch.empty_like(x)
+    assert _dd_call(L, w, x, d, y, pre, h, buf, D2, flag) == 0
+    assert np.abs(pre.cpu().numpy() - po).max() < TOL and np.abs(y.cpu().numpy() - yo).max() < TOL
+    assert np.abs(h.cpu().numpy() - ho).max() < TOL and np.abs(buf.cpu().numpy() - bo).max() < TOL
+    h2, buf2 = dev(h0), dev(b0)
+    ys, ps = [], []
+    for c0, c1 in ((0, 1000), (1000, 1200), (1200, T)):                 # the middle chunk is shorter than the delay line
+        xc, dc = x[:, c0:c1].contiguous(), d[:, c0:c1].contiguous()
+        yc, pc = torch.empty_like(xc), torch.empty_like(xc)
+        assert _dd_call(L, w, xc, dc, yc, pc, h2, buf2, D2, flag) == 0
+        ys.append(yc); ps.append(pc)
+    assert torch.equal(torch.cat(ys, 1), y) and torch.equal(torch.cat(ps, 1), pre)
+    assert torch.equal(h2, h) and torch.equal(buf2, buf)
+    # warm-up mode: y = pre_d, the buffer takes the tail of pre_d (code/model.py:288-292)
+    h3, buf3 = dev(h0), dev(b0)
+    yw, pw = torch.empty_like(x), torch.empty_like(x)
+    assert _dd_call(L, w, x, d, yw, pw, h3, buf3, D2, flag, warmup=1) == 0
+    assert torch.equal(yw, pw) and torch.equal(pw, pre) and torch.equal(buf3, pre[:, -D2:])
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+
+    # refused: pre_d aliasing y, or missing
+    assert _dd_call(L, w, x, d, y, y, h, buf, D2, flag) == -1 and b"distinct" in L.ntm_last_error()
+    assert L.ntm_diffdel_gru_forward(p(w["GRU.weight_ih_l0"]), p(w["GRU.weight_hh_l0"]), p(w["GRU.bias_ih_l0"]), p(w["GRU.bias_hh_l0"]),
+                                     p(w["output.weight"]), 64, p(x), p(d), p(y), None, B, T, p(h), p(buf), D2, 0, p(flag), None) == -1
+    # hidden size the library does not compile: refused through this entry as well
+    assert L.ntm_diffdel_gru_forward(p(w["GRU.weight_ih_l0"]), p(w["GRU.weight_hh_l0"]), p(w["GRU.bias_ih_l0"]), p(w["GRU.bias_hh_l0"]),
+                                     p(w["output.weight"]), 24, p(x), p(d), p(y), p(pre), B, T, p(h), p(buf), D2, 0, p(flag), None) == -1
+
+    # a delay beyond D in ONE stream: the flag goes up, the delay state of EVERY stream stays as it was (the reference
+    # asserts before it touches its buffer, code/model.py:284), the GRU state moves on (self.hidden is assigned at :412)
+    bad = ds.copy()
+    bad[5, 1234] = D2 + 0.25
+    hb, bufb = dev(h0), dev(b0)
+    assert _dd_call(L, w, x, dev(bad), y, pre, hb, bufb, D2, flag) == 0
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1 and torch.equal(bufb, dev(b0)) and torch.equal(hb, h)
+    # sticky: a later good call leaves the delay state frozen until the caller clears the flag
+    assert _dd_call(L, w, x, d, y, pre, hb, bufb, D2, flag) == 0
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1 and torch.equal(bufb, dev(b0))
+    flag.zero_()
+    hb = dev(h0)
+    assert _dd_call(L, w, x, d, y, pre, hb, bufb, D2, flag) == 0
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0 and torch.equal(bufb, buf) and np.abs(y.cpu().numpy() - yo).max() < TOL
+    # NaN counts as a violation too
+    bad = ds.copy()
+    bad[0, 0] = np.nan
+    assert _dd_call(L, w, x, dev(bad), y, pre, dev(h0), dev(b0), D2, flag) == 0
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1
+
+
+def test_c_abi_whole_hot_path_from_a_plain_cpp_process(ntm, tmp_path):
+    """tools/cabi/cabi_demo `diffdel` mode (C++, raw HIP allocations, no torch, no Python in the process):
+    ntm_diffdel_gru_forward in two chunks with carried state, the refusal, the range violation, then ntm_esr_sums --
+    against the oracle and bit for bit against the Python layer."""
+    exe = os.path.join(ROOT, "tools", "cabi", "cabi_demo.bin")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.dirname(exe)], check=True)
+    rng = np.random.default_rng(21)
+    B, T, D, split = 21, 1500, 301, 600
+    x = rng.uniform(-0.5, 0.5, (B, T)).astype(np.float32)
+    d = np.clip(120 + 100 * np.sin(np.arange(T)[None, :] / rng.uniform(40, 300, (B, 1))), 0, D).astype(np.float32)
+    x.tofile(str(tmp_path / "x.f32")); d.tofile(str(tmp_path / "d.f32"))
+    wfile = os.path.join(ROOT, "neural-tape-modeling_amd", "weights", "w2.bin")
+    r = subprocess.run([exe, "diffdel", wfile, str(tmp_path / "x.f32"), str(tmp_path / "d.f32"), str(B), str(T), str(D), str(split),
+                        str(tmp_path / "out")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "flag_after_good_calls=0 flag_after_violation=1 buffer_frozen=1" in r.stdout and "distinct buffer" in r.stdout
+    rd = lambda ext, dt, shape: np.fromfile(str(tmp_path / ("out." + ext)), dt).reshape(shape)     # noqa: E731
+    y, pre, h, buf = rd("y", np.float32, (B, T)), rd("pre", np.float32, (B, T)), rd("h", np.float32, (B, 64)), rd("buf", np.float32, (B, D))
+    esr = rd("esr", np.float64, (B, 2))
+    yo, po, ho, bo = oracle.diffdel_forward(oracle_weights(W_D), x, d, None, np.zeros((B, D), np.float32))
+    assert np.abs(pre - po).max() < TOL and np.abs(y - yo).max() < TOL and np.abs(h - ho).max() < TOL and np.abs(buf - bo).max() < TOL
+    so = oracle.esr_sums(y[:, split:], pre[:, split:])
+    assert np.abs(esr / so - 1).max() < 1e-9
+    md = ntm.DiffDelRNN(1, 64, 1, max_delay=D - 1)
+    md.load_state_dict(ntm.weights.load_state_dict(W_D))
+    md = md.to("cuda").eval()
+    md.initialize_hidden(B, D - 1)
+    y1, p1 = md(dev(x[:, :split]).unsqueeze(1), dev(d[:, :split]).unsqueeze(1))
+    y2, p2 = md(dev(x[:, split:]).unsqueeze(1), dev(d[:, split:]).unsqueeze(1))
+    assert np.array_equal(torch.cat([y1, y2], 2)[:, 0].cpu().numpy(), y) and np.array_equal(torch.cat([p1, p2], 2)[:, 0].cpu().numpy(), pre)
+
+
+# ----------------------------------------------------------------------------- eight ranks on the one GPU
+def _clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra)
+    return env
+
+
+def test_bench_eight_ranks_share_the_gpu_over_gloo():
+    """`python bench.py --gpus 8` (how the driver's 8-GPU node will start it, no launcher) with NTM_DIST_BACKEND=gloo so
+    that the eight ranks share this box's GPU: weak (8 x 64 segments), strong with an uneven split (500 = 4 x 63 + 4 x 62),
+    and a rank that dies after warm-up brings the whole job down, non-zero, well inside the timeout.
+    Reference counterpart: none (scripts/sbatch-train-exp1a.sh:7 runs replicas only)."""
+    import time
+    common = ["--gpus", "8", "--steps", "2", "--warmup", "1", "--samples", "4096", "--no-cpu-baseline", "--no-extra"]
+    env = _clean_env(NTM_DIST_BACKEND="gloo")
+    for extra, total in ((["--batch", "64"], 512), (["--scaling", "strong", "--total-batch", "500"], 500)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + extra, env=env, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 8 and out["ranks"] == 8 and out["backend"] == "gloo" and out["rccl_ranks"] == 0
+        assert [d["rank"] for d in out["rank_devices"]] == list(range(8)) and all(d["device"] == 0 for d in out["rank_devices"])
+        assert out["config"]["segments_total"] == total and out["checks"]["segments"] == total
+        assert out["config"]["segments_rank0"] == (64 if total == 512 else 63)
+        assert out["checks"]["esr_vs_first_pass"] == 0.0 and out["checks"]["every_timed_step_same_loss"] is True
+        assert abs(out["value"] - total * 4096 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
+        assert "other_workloads" not in out
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + ["--batch", "64", "--fail-rank", "5"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0 and "rank 5 exited with status 3" in r.stderr, r.stderr[-3000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert time.monotonic() - t0 < 300
+
+
+# ----------------------------------------------------------------------------- other_workloads of the default line
+def test_bench_line_carries_the_other_workloads():
+    """The default `bench.py --gpus 1` attaches configs[2], configs[3] and the GRU workload at other per-GPU batch sizes
+    as `other_workloads` (here at small shapes, `--other on`): each with kernel, kernel_ms, roofline.frac, determinism
+    and scattered streams against the oracle; the headline fields are those of a run without them."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "1040",
+                        "--samples", "4096", "--no-extra", "--other", "on", "--other-steps", "2", "--other-gru-batches", "2048,4112"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    ow = out["other_workloads"]
+    assert set(ow) == {"note", "diffdel", "tcn", "gru_B2048", "gru_B4112"} and "not a scaling curve" in ow["note"]
+    for k, v in ow.items():
+        if k == "note":
+            continue
+        assert v["kernel"] and v["kernel_ms"] > 0 and 0 < v["roofline"]["frac"] < 1.0 and v["roofline"]["kernel_ms"] == v["kernel_ms"]
+        assert v["checks"]["deterministic"] is True and len(v["checks"]["streams_checked"]) == 4
+        assert v["checks"]["vs_oracle_max_abs"] < TOL, (k, v["checks"])
+        assert v["kernel_ms"] <= v["device_ms_per_step"] <= v["ms_per_step"] * 1.001
+    assert ow["diffdel"]["bytes_per_sample"] == 16 and "1040 segments x 4096" in ow["diffdel"]["workload"]
+    assert "2048 segments x 4096" in ow["gru_B2048"]["workload"]
+    assert out["metric"].startswith("audio samples/sec") and out["cpu_baseline"]["value"] > 0 and out["checks"]["streams_vs_oracle"]["max_abs"] < TOL

@@ -10,6 +10,8 @@ import oracle
 from helpers import load, oracle_weights
 
 GRU_TOL = 2e-6
+W_G = "GRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE]_BEST"
+W_D = "DiffDelGRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE_WOWFLUTTER]_BEST"
 
 
 def test_g1_predict_real_material():
@@ -297,3 +299,43 @@ def test_g17_playback_fir_coefficients():
         b = Tape._compute_filter(ns)
         assert b.dtype == np.float64 and np.array_equal(b, g[f"b_{fs}_{n_fir}"])
     assert np.array_equal(oracle.fir_clamp(np.array([[0.5, 0.0, 3.0]]), [1.0, 0.5]), [[0.5, 0.25, 1.0]])
+
+
+def test_g18_validate_batched_inference():
+    """The reference's own RNN.validate / DiffDelRNN.validate (code/model.py:163-216, :513-616; golden g18,
+    tools/make_goldens_validate.py): the oracle driven the same way -- warm-up on the first INIT_LEN real samples
+    (DiffDel: warmup=True), the rest, the loss per batch (DiffDel: mean over 2048-sample pieces) -- reproduces the
+    reference's loss, examples and carried state."""
+    from helpers import validate_batches
+    g = load("g18_validate.npz")
+    fs = int(g["fs"])
+    batches = validate_batches(int(g["seed"]), int(g["n_batches"]), int(g["B"]), int(g["T"]), fs)
+
+    def esr(p, t):
+        p, t = p.astype(np.float32), t.astype(np.float32)
+        return float(((t - p) ** 2).mean(dtype=np.float32) / ((t ** 2).mean(dtype=np.float32) + np.float32(1e-5)))
+
+    w = oracle_weights(W_G)
+    tot = 0.0
+    for k, (x, t, _) in enumerate(batches):
+        _, h = oracle.gru_forward(w, x[:, 0, :1024])
+        y, h = oracle.gru_forward(w, x[:, 0, 1024:], h)
+        tot += esr(y, t[:, 0, 1024:])
+        assert np.abs(y[0] - g["rnn_pred"][k]).max() < 2e-6
+    assert abs(tot / len(batches) - float(g["rnn_val_loss"])) < 1e-5
+    assert np.abs(h - g["rnn_hidden"][0]).max() < 2e-6
+
+    wd = oracle_weights(W_D)
+    D = int(g["model_max_delay"]) + 1
+    init = 1 << (int(float(g["max_delay_s"]) * fs) - 1).bit_length()
+    assert init == 256
+    tot = 0.0
+    for k, (x, t, d) in enumerate(batches):
+        ds = (d.astype(np.float32) * np.float32(fs)).astype(np.float32)
+        _, _, h, buf = oracle.diffdel_forward(wd, x[:, 0, :init], ds[:, :init], None, np.zeros((x.shape[0], D), np.float32), warmup=True)
+        y, pre, h, buf = oracle.diffdel_forward(wd, x[:, 0, init:], ds[:, init:], h, buf)
+        n = int(np.ceil((x.shape[-1] - init) / 2048))
+        tot += sum(esr(y[:, i * 2048:(i + 1) * 2048], t[:, 0, init + i * 2048:init + (i + 1) * 2048]) for i in range(n)) / n
+        assert np.abs(pre[0] - g["dd_pre_d"][k]).max() < 5e-6 and np.abs(y[0] - g["dd_pred"][k]).max() < 5e-6
+    assert abs(tot / len(batches) - float(g["dd_val_loss"])) < 1e-5
+    assert np.abs(h - g["dd_hidden"][0]).max() < 5e-6 and np.abs(buf - g["dd_buffer"][:, 0]).max() < 5e-6

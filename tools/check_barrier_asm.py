@@ -17,15 +17,19 @@ import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "..", "neural-tape-modeling_amd", "csrc", "gru_mfma2.hip")
-LGKM = re.compile(r"^\s*(ds_|s_load_|s_buffer_load|s_memtime|s_memrealtime|s_sendmsg|s_scratch_load)")
+# everything that counts on lgkmcnt: LDS, scalar memory, messages -- and FLAT (flat_* increments both vmcnt and lgkmcnt and
+# returns out of order with LDS ops: a pointer whose address space the compiler could not infer would put one here), plus
+# scratch_* when the flat-scratch path is in use
+LGKM = re.compile(r"^\s*(ds_|s_load_|s_buffer_load|s_memtime|s_memrealtime|s_sendmsg|s_scratch_load|flat_|scratch_)")
 
 
-def main():
+def check(defines=()):
+    """Compile SRC with the product flags (+ `defines`) and check every non-diagnostic instantiation."""
     with tempfile.TemporaryDirectory() as tmp:
         asm = os.path.join(tmp, "k.s")
         subprocess.run(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(HERE, "..", "include"),
-                        "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form", "-S", "--cuda-device-only", "-o", asm, SRC],
-                       check=True, stderr=subprocess.DEVNULL)
+                        "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form", "-S", "--cuda-device-only", "-o", asm, SRC]
+                       + list(defines), check=True, stderr=subprocess.DEVNULL)
         text = open(asm).read()
     kernels = re.findall(r"^(_ZN3ntm16gru_mfma2_kernel\w+):[^\n]*\n(.*?)\n\s*\.amdhsa_kernel", text, flags=re.S | re.M)
     checked = 0
@@ -90,7 +94,12 @@ def main():
             tails += 1
         assert tails >= 2, f"{name}: only {tails} step tails found"
     assert checked >= 4, f"only {checked} step barriers checked"
-    print(f"check_barrier_asm: {checked} step barriers in {len(kernels)} instantiations: ok")
+    print(f"check_barrier_asm{' ' + ' '.join(defines) if defines else ''}: {checked} step barriers in {len(kernels)} instantiations: ok")
+
+
+def main():
+    check()                  # gru_mfma2.o of libntm.so
+    check(("-DNTM_LAB",))    # gru_mfma2_lab.o of libntm_lab.so: its non-diagnostic instantiations carry the same wait
 
 
 if __name__ == "__main__":
