@@ -124,7 +124,7 @@ def delay_trajectories(B, T, dev, max_delay):
     return d.clamp_(0, max_delay).unsqueeze(1)
 
 
-def measure_workload(workload, B, T, steps, warmup, check, dev, threads=1):
+def measure_workload(workload, B, T, steps, warmup, check, dev, threads=1, delay_mode="auto"):
     """One single-GPU workload beside the headline, `steps` timed passes over a resident batch of B distinct streams:
       "diffdel"  BASELINE configs[2]: DiffDelGRU-HS[64] (CHOWTAPE_WOWFLUTTER weights, D = 1847) predict
       "tcn"      BASELINE configs[3]: the TCN contrast point
@@ -140,6 +140,7 @@ def measure_workload(workload, B, T, steps, warmup, check, dev, threads=1):
     d = None
     if workload == "diffdel":
         model = ntm_amd.harness.build_model(weights.W_DIFFDEL, max_delay_seconds=0.0335, device=dev)   # D = 1847
+        model.delay_mode = delay_mode
         d = delay_trajectories(B, T, dev, model.max_delay)
         run = lambda: model.predict(x, d, _events=kev)[0]                    # noqa: E731
         name, bytes_per_sample, fl = "DiffDelGRU-HS[64] CHOWTAPE_WOWFLUTTER weights, D=1847", 16, FLOP_PER_SAMPLE
@@ -177,6 +178,7 @@ def measure_workload(workload, B, T, steps, warmup, check, dev, threads=1):
             ref = oracle.gru_predict(sd(weights.W_GRU), xs, threads=threads)[0]
     for _ in range(max(warmup, 1)):
         y0 = run()
+    y = run()          # one more untimed pass: the determinism target y0 stays alive, so the allocator needs one more block
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ms, k1, k2 = [], [], []
@@ -194,14 +196,38 @@ def measure_workload(workload, B, T, steps, warmup, check, dev, threads=1):
             "frac": fl * B * T / ksec / 1e12 / PEAK_FP32_TFLOPS, "traffic": None, "flop_per_sample": fl,
             "kernel": kernel, "kernel_ms": 1e3 * ksec}
     if workload == "diffdel":
-        # K2 as a separate streaming pass: pre_d and d read once, y written once = 12 algorithmic bytes per sample
-        # (the two gathered taps come from pre_d, i.e. from the same bytes); the carried buffer adds 8 D bytes per stream
-        dsec = float(np.mean(k2)) * 1e-3
-        alg = 12.0 * B * T + 8.0 * B * model.diffdel.max_delay
-        roof["delay_line"] = {"bound": "hbm", "kernel": "delay_apply_kernel + delay_update_kernel", "kernel_ms": 1e3 * dsec,
-                              "achieved": alg / dsec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                              "frac": alg / dsec / 1e9 / PEAK_HBM_GBS, "bytes_per_sample": 12,
-                              "frac_at_16B_per_sample": 16.0 * B * T / dsec / 1e9 / PEAK_HBM_GBS}
+        fused = model.delay_mode != "two_pass" and model.kernel_variant == "auto" and B > 1024
+        if fused:
+            # ONE launch for the step: the delay line interpolates the kernel's own pre_d output inside the y-tile
+            # housekeeping (taps through L2), so the step's HBM traffic is its 16 algorithmic bytes per sample; the events
+            # bracket the fused launch + the small buffer-update launch behind it.  The two-pass form (GRU launch, then
+            # the streaming delay pass: 12 more bytes per sample) is timed beside it for the A/B.
+            roof["kernel"] = kernel = "gru_mfma2_kernel<FUSE: GRU + head + delay line> (+ delay_update_kernel)"
+            roof["hbm_bytes_per_sample"] = 16
+            model.delay_mode = "two_pass"
+            t1, g1, d1 = [], [], []
+            for i in range(1 + steps):
+                ev0.record(); y2 = run(); ev1.record(); torch.cuda.synchronize()
+                if i:
+                    t1.append(ev0.elapsed_time(ev1)); g1.append(kev[0].elapsed_time(kev[1])); d1.append(kev[1].elapsed_time(kev[2]))
+            dsec = float(np.mean(d1)) * 1e-3
+            alg = 12.0 * B * T + 8.0 * B * model.diffdel.max_delay
+            roof["two_pass"] = {"device_ms_per_step": float(np.mean(t1)), "gru_kernel_ms": float(np.mean(g1)),
+                                "delay_pass_ms": 1e3 * dsec, "delay_pass_kernel": "delay_apply_kernel + delay_update_kernel",
+                                "delay_pass_hbm": {"achieved": alg / dsec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                                   "frac": alg / dsec / 1e9 / PEAK_HBM_GBS, "bytes_per_sample": 12},
+                                "identical_output": bool(torch.equal(y2, y))}
+            model.delay_mode = "auto"
+            del y2
+        else:
+            # K2 as a separate streaming pass: pre_d and d read once, y written once = 12 algorithmic bytes per sample
+            # (the two gathered taps come from pre_d, i.e. from the same bytes); the carried buffer adds 8 D bytes per stream
+            dsec = float(np.mean(k2)) * 1e-3
+            alg = 12.0 * B * T + 8.0 * B * model.diffdel.max_delay
+            roof["delay_line"] = {"bound": "hbm", "kernel": "delay_apply_kernel + delay_update_kernel", "kernel_ms": 1e3 * dsec,
+                                  "achieved": alg / dsec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                  "frac": alg / dsec / 1e9 / PEAK_HBM_GBS, "bytes_per_sample": 12,
+                                  "frac_at_16B_per_sample": 16.0 * B * T / dsec / 1e9 / PEAK_HBM_GBS}
     res = {"workload": f"{name}, {B} segments x {T} samples fp32", "value": B * T * steps / elapsed, "unit": "samples/s",
            "steps": steps, "warmup": max(warmup, 1), "ms_per_step": 1e3 * elapsed / steps,
            "device_ms_per_step": float(np.mean(ms)), "bytes_per_sample": bytes_per_sample,
@@ -220,7 +246,7 @@ def side_workload(a):
     with its event-timed launch duration; for the DiffDelGRU step the HBM roofline of the delay-line pass sits beside it."""
     assert torch.cuda.is_available()
     r = measure_workload(a.workload, a.batch, a.samples, a.steps, a.warmup, not a.no_cpu_baseline, torch.device("cuda", 0),
-                         threads=_host_threads())
+                         threads=_host_threads(), delay_mode=a.delay_mode)
     print(json.dumps({
         "metric": f"audio samples/sec (44.1 kHz) {a.workload}, batch={a.batch}x{a.samples}", "value": r["value"],
         "unit": "samples/s", "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": r["ms_per_step"],
@@ -383,6 +409,8 @@ def main():
     ap.add_argument("--other", default="auto", choices=["auto", "on", "off"],
                     help="attach `other_workloads` (configs[2], [3] and the per-GPU shapes of configs[4]) to the line: "
                          "auto = only for the default single-GPU workload (4096 x 65536)")
+    ap.add_argument("--delay-mode", default="auto", choices=["auto", "two_pass", "fused"],
+                    help="--workload diffdel: the fused DiffDelRNN step (auto: where the matrix-pipe kernel runs) or GRU launch + delay pass")
     ap.add_argument("--other-steps", type=int, default=3)
     ap.add_argument("--other-gru-batches", type=lambda v: [int(t) for t in v.split(",") if t], default=[8192, 16384, 32768])
     ap.add_argument("--workload", default="gru", choices=["gru", "diffdel", "tcn"],

@@ -32,7 +32,7 @@ extern "C" {
 #define NTM_EHIP (-2)    /* HIP runtime error (launch failed, no device)               */
 #define NTM_EDELAY (-3)  /* reserved for host-side delay-range checks                  */
 
-#define NTM_ABI_VERSION 3 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag.  3: the TCN scratch is padded (ntm_tcn_scratch_floats grew), dilation / length limits */
+#define NTM_ABI_VERSION 4 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag.  3: the TCN scratch is padded (ntm_tcn_scratch_floats grew), dilation / length limits.  4: ntm_diffdel_gru_forward is ONE fused launch where the matrix-pipe kernel runs (+ ntm_diffdel_gru_forward_ex) */
 
 #define NTM_HIDDEN 64 /* hidden size of every shipped checkpoint (HS[64]): matrix-pipe and low-latency kernels.
                          H = 8, 16, 32 (the reference's constructor default is 8, code/model.py:22; its training
@@ -101,14 +101,30 @@ int ntm_delay_forward(const float *x, const float *d, float *y, int64_t B, int64
 
 /*
  * Replaces DiffDelRNN.forward(x, del_traj, warmup), code/model.py:393-424:
- * the GRU + bias-free head writes pre_d, then the delay line writes y.  Returns (y, pre_d)
- * through the two output pointers; h_state and dl_state as above.
+ * the GRU + bias-free head writes pre_d, the delay line writes y.  Returns (y, pre_d) through the two
+ * output pointers (distinct buffers, neither aliasing x); x, d, y, pre_d [B,T] contiguous; h_state, dl_state,
+ * err_flag as above (a violation leaves dl_state untouched; h_state is h_T either way -- the reference assigns
+ * self.hidden at :412 before its delay line asserts).
+ *
+ * Where the matrix-pipe kernel runs (H = 64, B > NTM_GRU_LAT_MAX_B) the step is ONE fused launch: the delay line
+ * interpolates the kernel's own pre_d output inside the y-tile housekeeping of the recurrence, one 64-sample tile
+ * behind it (taps read back through L2; d is read once, pre_d is never re-read from HBM), bit-identical to the separate
+ * pass on the same pre_d; a small launch moves the carried buffer on afterwards.  Small batches and H < 64 run the GRU
+ * launch followed by the streaming delay pass (NTM_DIFFDEL_TWO_PASS).  ntm_diffdel_gru_forward = mode NTM_DIFFDEL_AUTO.
  */
+#define NTM_DIFFDEL_AUTO 0     /* fused where the matrix-pipe kernel runs, two passes elsewhere          */
+#define NTM_DIFFDEL_TWO_PASS 1 /* ntm_gru_forward then ntm_delay_forward                                 */
+#define NTM_DIFFDEL_FUSED 2    /* the fused kernel for every stream (H = 64), whatever B is (tests, A/B) */
 int ntm_diffdel_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih,
                             const float *b_hh, const float *w_o, int H, const float *x,
                             const float *d, float *y, float *pre_d, int64_t B, int64_t T,
                             float *h_state, float *dl_state, int D, int warmup, int32_t *err_flag,
                             void *stream);
+int ntm_diffdel_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih,
+                               const float *b_hh, const float *w_o, int H, const float *x,
+                               const float *d, float *y, float *pre_d, int64_t B, int64_t T,
+                               float *h_state, float *dl_state, int D, int warmup, int32_t *err_flag,
+                               int mode, void *stream);
 
 /*
  * Per-stream sums for the ESR loss that follows the path in code/test-model.py:250-254,386-388

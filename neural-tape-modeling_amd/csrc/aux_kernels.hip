@@ -1,6 +1,7 @@
 // K2 (time-varying fractional delay line) and K3 (ESR partial sums): streaming kernels, coalesced
 // 4-16 B/lane global accesses, no MFMA.  (K4, the TCN, lives in tcn_kernels.hip.)
 #include "ntm_common.h"
+#include "delay_math.h"
 
 namespace ntm {
 
@@ -17,40 +18,6 @@ namespace ntm {
 // The flag is STICKY and caller-owned: once it is non-zero every later K2 launch on it is a no-op (state frozen at
 // the last good call) until the caller clears it -- the host checks it when it wants to (once per predict), not per call.
 // ---------------------------------------------------------------------------------------
-typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at 4-byte alignment
-
-// one output sample: y[n] = w_b x[n-k-1] + w_a x[n-k] with the reference's tap order and rounding
-__device__ __forceinline__ float delay_sample(const float *xb, const float *bb, int D, int64_t n, float dn)
-{
-#pragma clang fp contract(off)   // products and the sum must round separately (bit-exact parity)
-    const float kf = floorf(dn);
-    float acc = 0.0f;
-#pragma unroll
-    for (int tap = 1; tap >= 0; --tap) {          // m = k+1 first, then m = k (reference sum order)
-        const float mf = kf + (float)tap;
-        if (mf < 0.0f || mf > (float)D) continue;
-        const float w = 1.0f - fabsf(mf - dn);
-        if (!(w > 0.0f)) continue;
-        const int64_t src = n - (int64_t)mf;
-        const float xv = src >= 0 ? xb[src] : bb[D + src];
-        const float prod = w * xv;
-        acc = acc + prod;
-    }
-    return acc;
-}
-
-// the same sample when both taps are known to lie inside x and inside [0, D]: xa = x[n-k], xb1 = x[n-k-1]
-__device__ __forceinline__ float delay_sample_fast(float dn, float kf, float xa, float xb1)
-{
-#pragma clang fp contract(off)
-    float acc = 0.0f;
-    const float wb = 1.0f - fabsf((kf + 1.0f) - dn);
-    if (wb > 0.0f) { const float prod = wb * xb1; acc = acc + prod; }
-    const float wa = 1.0f - fabsf(kf - dn);
-    if (wa > 0.0f) { const float prod = wa * xa; acc = acc + prod; }
-    return acc;
-}
-
 // A 256-thread workgroup covers DG runs of 1024 consecutive samples of one stream; in a run thread i owns the 4
 // samples 4i..4i+3, so every 16-byte access of a wavefront (d load, tap window, y store) is lane-contiguous -- 1 KB per
 // instruction, fully coalesced; the d loads of all runs are issued before anything else.
@@ -167,8 +134,9 @@ __global__ __launch_bounds__(DU_THREADS) void delay_update_kernel(const float *x
     for (int i = keep + threadIdx.x; i < D; i += DU_THREADS) bb[i] = xb[x0 + (i - keep)];
 }
 
-hipError_t launch_delay(const float *x, const float *d, float *y, int64_t B, int64_t T, float *dl_state, int D,
-                        int warmup, int32_t *err_flag, hipStream_t stream)
+// the interpolation alone (the carried buffer is read, not moved on)
+hipError_t launch_delay_apply(const float *x, const float *d, float *y, int64_t B, int64_t T, const float *dl_state, int D,
+                              int warmup, int32_t *err_flag, hipStream_t stream)
 {
     if (B == 0 || T == 0) return hipSuccess;
     if (T > 0x7fffffffLL - DRUN * DG) return hipErrorInvalidValue;      // 32-bit sample indices inside a stream
@@ -177,8 +145,27 @@ hipError_t launch_delay(const float *x, const float *d, float *y, int64_t B, int
     if (nblk > 0x7fffffffLL) return hipErrorInvalidValue;
     hipLaunchKernelGGL(delay_apply_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, stream, x, d, y, B, (int)T, dl_state, D,
                        warmup, err_flag, (unsigned)tiles);
+    return hipGetLastError();
+}
+
+hipError_t launch_delay(const float *x, const float *d, float *y, int64_t B, int64_t T, float *dl_state, int D,
+                        int warmup, int32_t *err_flag, hipStream_t stream)
+{
+    if (B == 0 || T == 0) return hipSuccess;
+    hipError_t e = launch_delay_apply(x, d, y, B, T, dl_state, D, warmup, err_flag, stream);
+    if (e != hipSuccess) return e;
     if (D > 0)
         hipLaunchKernelGGL(delay_update_kernel, dim3((unsigned)B), dim3(DU_THREADS), 0, stream, x, dl_state, T, D, err_flag);
+    return hipGetLastError();
+}
+
+// the buffer update alone: behind the fused DiffDelRNN kernel (gru_mfma2.hip, FUSE), which interpolates but leaves the
+// carried buffer to this launch -- it has to see the range flag of EVERY workgroup of that kernel
+hipError_t launch_delay_update(const float *x, int64_t B, int64_t T, float *dl_state, int D, const int32_t *err_flag,
+                               hipStream_t stream)
+{
+    if (B == 0 || T == 0 || D <= 0) return hipSuccess;
+    hipLaunchKernelGGL(delay_update_kernel, dim3((unsigned)B), dim3(DU_THREADS), 0, stream, x, dl_state, T, D, err_flag);
     return hipGetLastError();
 }
 

@@ -25,6 +25,7 @@
 //   * PRESCALE (default on): -log2(e) resp. 2 log2(e) are folded into W_hh / W_ih / biases when they
 //     are loaded, so sigmoid and tanh start directly with v_exp_f32 (saves 12 VALU ops per step).
 #include "ntm_common.h"
+#include "delay_math.h"
 
 #include <atomic>
 #include <cstdlib>
@@ -131,7 +132,23 @@ __device__ __forceinline__ f32x4 pack_hl(const f16x4 hi, const f16x4 lo)
 // YPN = 4: the four lane groups of a wave are summed first (two permlane swaps), 4 planes, 53 KB of LDS:
 //   two or three workgroups share a CU and one group's MFMAs overlap another group's gate math
 //   (overlap only exists across waves) -- used when B >= 8192.
-template <bool PRESCALE, bool STAMP, int ABL = 0, int ENGINE = 0, int YPN = 16>
+// FUSE = true: the DiffDelRNN step (code/model.py:393-424) in ONE launch.  `a.y` is then pre_d (the GRU + bias-free head)
+//   and the time-varying delay line (code/model.py:269-320) writes a.yd from it inside the y-tile housekeeping, one
+//   64-sample tile behind the recurrence and spread over three compile-time positions of a tile so that no load
+//   latency lands on the recurrence's critical path:
+//     phase  2 of tile i    the thread's 4 delays of tile i-1 are fetched (next to the flush that stores pre_d tile i-1);
+//                           before that, the taps fetched for tile i-2 are consumed and y tile i-2 is stored;
+//     phase 34              s_waitcnt vmcnt(0): every thread's pre_d stores of tile i-1 have completed, and the barrier
+//                           of step 35 orders them before any load issued after it (one workgroup = one CU = one L1);
+//     phase 36              the delays are classified and the taps of tile i-1 fetched FROM THE KERNEL'S OWN pre_d
+//                           OUTPUT (L2: the taps lie at most D samples back): the two taps of a sample are adjacent,
+//                           one 8-byte load per sample at 4-byte alignment, when all 4 delays lie in [0, D) and no
+//                           tap falls into the carried history -- whatever the integer parts do; everything else
+//                           (history taps, k = D, d < 0, NaN, d > D) takes delay_sample() at consume time.
+//   The arithmetic is delay_math.h's, i.e. bit-identical to the separate pass (delay_apply_kernel) on the same pre_d.
+//   The range check (d > D or NaN: the reference's assert, code/model.py:284) raises the caller's sticky flag; the
+//   carried buffer is moved on by delay_update_kernel afterwards (it must see the flag of EVERY workgroup).
+template <bool PRESCALE, bool STAMP, int ABL = 0, int ENGINE = 0, int YPN = 16, bool FUSE = false>
 __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 {
     using namespace m2;
@@ -246,7 +263,99 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
                 for (int c = 0; c < 4; ++c)
                     if (gt + c < T) dst[c] = v[c];
             }
+            if constexpr (FUSE) {
+                if (a.warmup) {          // warm-up mode: the delay line passes pre_d through (code/model.py:288-292)
+                    float *dw = a.yd + gs * T + gt;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (gt + c < T) dw[c] = v[c];
+                }
+            }
         }
+    };
+
+    // ---- FUSE: the delay line, one tile behind the recurrence (see the comment above the kernel) ----------------
+    // thread -> stream tid>>4, samples 4*(tid&15)..+3 of a tile, as in the flush.  All addresses are the workgroup's
+    // uniform row-block base + a 32-bit element offset (the launcher bounds 16 T below 2^31).
+    const bool dl_row = FUSE && (s0 + (tid >> 4)) < a.B;
+    // the workgroup's 16 rows of pre_d / d / y as wave-uniform BYTE bases + 32-bit byte offsets (the launcher bounds
+    // 64 T below 2^32): the accesses take the scalar-base addressing mode, one v_add per address
+    const char *const dl_xw = FUSE ? (const char *)(a.y + s0 * a.ys) : nullptr;     // pre_d (ys == T)
+    const char *const dl_dw = FUSE ? (const char *)(a.dd + s0 * T) : nullptr;
+    char *const dl_yw = FUSE ? (char *)(a.yd + s0 * T) : nullptr;
+    const int dl_T = (int)T;
+    const unsigned dl_ro = dl_row ? (unsigned)(tid >> 4) * (unsigned)dl_T * 4u : 0u;  // byte offset of this thread's row (an
+                                                                                     // absent stream reads row 0, stores nothing)
+    // the delay part runs unless this is a warm-up call or an earlier violation froze the state (sticky flag)
+    const bool dl_on = FUSE && !a.warmup && !(a.dl_flag && *a.dl_flag);
+    const unsigned dl_dbits = __float_as_uint((float)a.D);                   // 0 <= d < D  <=>  bits(d) < bits(D) (unsigned)
+    f32x4 dl_d = {0.0f, 0.0f, 0.0f, 0.0f};                                   // the 4 delays of the tile in flight
+    f32x2u dl_t0 = {0.0f, 0.0f}, dl_t1 = dl_t0, dl_t2 = dl_t0, dl_t3 = dl_t0; // (x[n-k-1], x[n-k]) of its 4 samples
+    bool dl_fast = false;
+    int dl_bad = 0;
+    int dl_tile = 0;                                                         // tile in flight (wave-uniform)
+    int dl_stage = 0;                                                        // 0 nothing in flight, 1 delays fetched, 2 taps fetched
+    (void)dl_xw; (void)dl_dw; (void)dl_yw; (void)dl_ro; (void)dl_on; (void)dl_dbits; (void)dl_fast; (void)dl_bad;
+    // Each of the three stages holds ONE global access per array on its common path (16-byte accesses at 4-byte alignment,
+    // so rows need no alignment): hipcc's wait insertion merges the pending-load state of every branch of a step, and a
+    // second, conditional load path into the same registers made it drain the VM counter in front of the common one.
+    // WHOLE (compile time): the tile lies entirely inside [0, T) -- true at the housekeeping positions of the unrolled
+    // whole-tile loop, whose delay tile is an earlier one -- so no bound on T is tested; otherwise the ragged tail of a
+    // row (its last T % 4 samples) is left to the general form entirely.
+    auto dl_load_d = [&](int tile, auto whole_c) { // stage 0 -> 1
+        constexpr bool WHOLE = decltype(whole_c)::value;
+        const int gt = tile * TT + 4 * (tid & 15);
+        if (WHOLE || gt + 3 < dl_T) dl_d = *(const f32x4u *)(dl_dw + (dl_ro + 4u * (unsigned)gt));
+        dl_tile = tile;
+        dl_stage = 1;
+    };
+    auto dl_issue_taps = [&](auto whole_c) {       // stage 1 -> 2: pre_d up to the end of dl_tile is visible
+        constexpr bool WHOLE = decltype(whole_c)::value;
+        const int gt = dl_tile * TT + 4 * (tid & 15);
+        // sample c = output n = gt + c with integer part k_c: its taps x[n-k-1], x[n-k] are ONE 8-byte load at element
+        // i_c = n - k - 1.  Fast when every d lies in [0, D) (then k + 1 <= D; NaN and negative values fail the unsigned
+        // compare of the bit patterns) and every i_c >= 0 (no tap in the carried history); i_c + 1 = n - k <= n < T.
+        // (__float_as_uint, not __builtin_bit_cast: hipcc of ROCm 7.2 folds a bit_cast of an ext-vector ELEMENT to element 0)
+        const int i0 = gt - 1 - (int)floorf(dl_d[0]), i1 = gt - (int)floorf(dl_d[1]);
+        const int i2 = gt + 1 - (int)floorf(dl_d[2]), i3 = gt + 2 - (int)floorf(dl_d[3]);
+        const unsigned b0 = __float_as_uint(dl_d[0]), b1 = __float_as_uint(dl_d[1]);
+        const unsigned b2 = __float_as_uint(dl_d[2]), b3 = __float_as_uint(dl_d[3]);
+        const unsigned bmax = max(max(b0, b1), max(b2, b3));
+        const int imin = min(min(i0, i1), min(i2, i3));
+        dl_fast = bmax < dl_dbits && imin >= 0 && (WHOLE || gt + 3 < dl_T);
+        // unconditional loads (lanes off the fast path read the row's first samples: harmless, in range for T >= 2)
+        if (WHOLE || dl_T >= 2) {
+            dl_t0 = *(const f32x2u *)(dl_xw + (dl_ro + 4u * (unsigned)(dl_fast ? i0 : 0)));
+            dl_t1 = *(const f32x2u *)(dl_xw + (dl_ro + 4u * (unsigned)(dl_fast ? i1 : 0)));
+            dl_t2 = *(const f32x2u *)(dl_xw + (dl_ro + 4u * (unsigned)(dl_fast ? i2 : 0)));
+            dl_t3 = *(const f32x2u *)(dl_xw + (dl_ro + 4u * (unsigned)(dl_fast ? i3 : 0)));
+        }
+        dl_stage = 2;
+    };
+    // stage 2 -> 0 in two halves, because hipcc also drains the VM counter between a global STORE and a later global
+    // LOAD: a step issues all its loads first, then all its stores.
+    f32x4 dl_out = {0.0f, 0.0f, 0.0f, 0.0f};
+    int dl_out_gt = 0;
+    bool dl_out_full = false;
+    auto dl_compute = [&](auto whole_c) {          // y of dl_tile into registers (consumes the taps and the delays)
+        constexpr bool WHOLE = decltype(whole_c)::value;
+        const int gt = dl_tile * TT + 4 * (tid & 15);
+        dl_stage = 0;
+        dl_out = (f32x4){delay_pair(dl_d[0], dl_t0), delay_pair(dl_d[1], dl_t1), delay_pair(dl_d[2], dl_t2), delay_pair(dl_d[3], dl_t3)};
+        dl_out_gt = gt;
+        dl_out_full = dl_row && (WHOLE || gt + 3 < dl_T);
+        const bool gen = dl_row && (WHOLE || gt < dl_T) && !dl_fast;
+        if (__any(gen)) {
+            // rare (never under wow and flutter once n > k): history taps, k = D, d < 0, NaN, d > D, and the ragged tail of
+            // a row, whose delays are fetched and whose outputs are stored right here
+            if (gen)
+                delay_general4((const float *)(dl_xw + dl_ro), (const float *)(dl_dw + dl_ro), (float *)(dl_yw + dl_ro),
+                               a.dl_buf + (s0 + (tid >> 4)) * (int64_t)a.D, a.D, gt, dl_T, dl_out_full, dl_d, dl_out, dl_bad);
+        }
+    };
+    auto dl_store = [&]() {
+        if (dl_out_full) *(f32x4u *)(dl_yw + (dl_ro + 4u * (unsigned)dl_out_gt)) = dl_out;
+        dl_out_full = false;
     };
 
     float xr[4];
@@ -405,11 +514,30 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         // visible once step 64i+65 has passed its barrier)
         if constexpr (!(ABL & 32)) {
             if (HK == 1 || (HK < 0 && ph == 2)) {
+                if constexpr (FUSE) {
+                    // y of the tile whose taps were fetched at phase 36 of the previous tile, into registers; below, this
+                    // tile's delays -- every load of the step ahead of every store.
+                    // The wait is the BUILTIN (vmcnt(0) only: simm16 0x0F70 leaves expcnt / lgkmcnt alone) so that hipcc's
+                    // own wait bookkeeping sees it: with the taps' consumers behind run-time stage tests it otherwise
+                    // keeps "a load into these registers may be pending" alive around the loop and drains the VM counter
+                    // in front of the NEXT loads -- the x tile fetched just before them, a full memory round trip.
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                    if (dl_stage == 2) dl_compute(std::bool_constant<(HK > 0)>{});
+                }
                 // the x loads go out before the flush's stores (no VMEM drain between them)
                 if ((tile + 1) * TT < T) load_x_tile(tile + 1, xr);
+                if constexpr (FUSE) {
+                    if (dl_on && t > 65) dl_load_d((int)next_flush, std::bool_constant<(HK > 0)>{});
+                    dl_store();
+                }
                 if (t > 65) { flush_y_tile(next_flush); ++next_flush; }
             } else if (HK == 2 || (HK < 0 && ph == 34)) {
                 if ((tile + 1) * TT < T) store_x_tile(tile + 1, xr);
+                // FUSE: this thread's pre_d stores of phase 2 have completed; step 35's barrier makes that true of the
+                // whole workgroup before phase 36 reads them back
+                if constexpr (FUSE) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), as a MachineInstr hipcc accounts for
+            } else if (FUSE && (HK == 3 || (HK < 0 && ph == 36))) {
+                if (dl_stage == 1) dl_issue_taps(std::bool_constant<(HK > 0)>{});
             }
         }
 
@@ -497,6 +625,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         using H0 = std::integral_constant<int, 0>;
         using HA = std::integral_constant<int, 1>;
         using HB = std::integral_constant<int, 2>;
+        using HC = std::integral_constant<int, 3>;
         using HR = std::integral_constant<int, -1>;
         const int64_t full = (T / TT) * TT;
         for (int64_t t0 = 0; t0 < full; t0 += TT) {          // whole tiles: housekeeping at compile-time positions
@@ -504,7 +633,12 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
             step(t0 + 2, C0{}, HA{}); step(t0 + 3, C1{}, H0{});
             for (int p = 4; p < 34; p += 2) { step(t0 + p, C0{}, H0{}); step(t0 + p + 1, C1{}, H0{}); }
             step(t0 + 34, C0{}, HB{}); step(t0 + 35, C1{}, H0{});
-            for (int p = 36; p < TT; p += 2) { step(t0 + p, C0{}, H0{}); step(t0 + p + 1, C1{}, H0{}); }
+            if constexpr (FUSE) {
+                step(t0 + 36, C0{}, HC{}); step(t0 + 37, C1{}, H0{});
+                for (int p = 38; p < TT; p += 2) { step(t0 + p, C0{}, H0{}); step(t0 + p + 1, C1{}, H0{}); }
+            } else {
+                for (int p = 36; p < TT; p += 2) { step(t0 + p, C0{}, H0{}); step(t0 + p + 1, C1{}, H0{}); }
+            }
         }
         for (int64_t t = full; t < T; t += 2) {               // ragged last tile: phase tests at run time
             step(t, C0{}, HR{});
@@ -519,6 +653,24 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     // ---- epilogue: remaining y tiles, final state ---------------------------------------------------
     __syncthreads();
     while (next_flush * TT < T) { flush_y_tile(next_flush); ++next_flush; }
+    if constexpr (FUSE) {
+        if (dl_on) {
+            // every pre_d tile is stored: make the stores visible to the workgroup, then run the delay tiles that are left
+            // (the one in flight first) back to back -- at most two tiles plus the ragged tail per launch
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int next_delay = 0;
+            if (dl_stage == 1) dl_issue_taps(std::false_type{});
+            if (dl_stage == 2) { next_delay = dl_tile + 1; dl_compute(std::false_type{}); dl_store(); }
+            for (; (int64_t)next_delay * TT < T; ++next_delay) {
+                dl_load_d(next_delay, std::false_type{});
+                dl_issue_taps(std::false_type{});
+                dl_compute(std::false_type{});
+                dl_store();
+            }
+            if (a.dl_flag && __any(dl_bad) && l == 0) atomicOr(a.dl_flag, 1);
+        }
+    }
 
     if (a.h_state && valid) {
 #pragma unroll
@@ -573,6 +725,20 @@ hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream)
                     : NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 1, 16>), smem16);
     return many ? NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 4>), smem4)
                 : NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 16>), smem16);
+}
+
+// The DiffDelRNN step in one launch (exact fp32 engine).  The carried delay buffer is moved on by delay_update_kernel
+// (aux_kernels.hip) behind this launch.
+hipError_t launch_gru_mfma2_fused(const GruArgs &a, hipStream_t stream)
+{
+    constexpr size_t smem16 = m2::smem_floats(16) * sizeof(float);
+    constexpr size_t smem4 = m2::smem_floats(4) * sizeof(float);
+    if (!a.dd || !a.yd || (a.D > 0 && !a.dl_buf) || a.abl || a.dbg || a.engine) return hipErrorInvalidValue;
+    if (a.T >= (1LL << 26) || a.ys != a.T) return hipErrorInvalidValue;   // contiguous rows; 32-bit BYTE offsets inside a 16-row block
+    const unsigned grid = (unsigned)((a.B + m2::SG - 1) / m2::SG);
+    const bool many = grid > (unsigned)device_cus();
+    return many ? NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 4, true>), smem4)
+                : NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 16, true>), smem16);
 }
 
 #ifdef NTM_LAB

@@ -9,6 +9,10 @@
 namespace ntm {
 hipError_t launch_delay(const float *x, const float *d, float *y, int64_t B, int64_t T, float *dl_state, int D,
                         int warmup, int32_t *err_flag, hipStream_t stream);
+hipError_t launch_delay_apply(const float *x, const float *d, float *y, int64_t B, int64_t T, const float *dl_state, int D,
+                              int warmup, int32_t *err_flag, hipStream_t stream);
+hipError_t launch_delay_update(const float *x, int64_t B, int64_t T, float *dl_state, int D, const int32_t *err_flag,
+                               hipStream_t stream);
 hipError_t launch_esr(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int splits, double *out,
                       hipStream_t stream);
 int esr_default_splits(int64_t B, int64_t T, int64_t skip);
@@ -123,15 +127,69 @@ int ntm_delay_forward(const float *x, const float *d, float *y, int64_t B, int64
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_delay_forward");
 }
 
+int ntm_diffdel_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                               const float *w_o, int H, const float *x, const float *d, float *y, float *pre_d,
+                               int64_t B, int64_t T, float *h_state, float *dl_state, int D, int warmup,
+                               int32_t *err_flag, int mode, void *stream)
+{
+    if (!pre_d || pre_d == y) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: pre_d must be a distinct buffer");
+    if (mode != NTM_DIFFDEL_AUTO && mode != NTM_DIFFDEL_TWO_PASS && mode != NTM_DIFFDEL_FUSED)
+        return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: unknown mode");
+    if (mode == NTM_DIFFDEL_FUSED && H != NTM_HIDDEN)
+        return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: the fused kernel is compiled for hidden size 64 only");
+    // how many streams take the fused matrix-pipe kernel: all of them when forced; under AUTO the streams
+    // ntm_gru_forward would give to that kernel (B > NTM_GRU_LAT_MAX_B; a remainder of at most that many streams behind
+    // whole device rounds goes to the low-latency kernel + the streaming delay pass, as there)
+    int64_t fused = 0;
+    constexpr int64_t kFusedMaxT = (int64_t)1 << 26;     // the fused kernel addresses a 16-row block with 32-bit byte offsets
+    if (mode == NTM_DIFFDEL_FUSED) {
+        if (T >= kFusedMaxT) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: the fused kernel takes T < 2^26 samples per call");
+        fused = B;
+    } else if (mode == NTM_DIFFDEL_AUTO && H == NTM_HIDDEN && B > NTM_GRU_LAT_MAX_B && T < kFusedMaxT) {
+        const int64_t round = 16 * (int64_t)ntm::device_cus();
+        const int64_t full = (B / round) * round, rem = B - full;
+        fused = (full > 0 && rem > 0 && rem <= NTM_GRU_LAT_MAX_B) ? full : B;
+    }
+    if (fused > 0) {
+        if (B < 0 || T < 0 || D < 0) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: negative size");
+        if (T == 0) return NTM_OK;
+        if (!w_ih || !w_hh || !b_ih || !b_hh || !w_o || !x || !d || !y || (D > 0 && !dl_state))
+            return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: null pointer");
+        if (x == y || x == pre_d) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: outputs must not alias x");
+        ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, nullptr, x, pre_d, h_state, fused, T, T, T, nullptr, 0, 0};
+        a.dd = d;
+        a.yd = y;
+        a.dl_buf = dl_state;
+        a.dl_flag = err_flag;
+        a.D = D;
+        a.warmup = warmup;
+        hipError_t e = ntm::launch_gru_mfma2_fused(a, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "ntm_diffdel_gru_forward");
+    }
+    if (fused < B) {            // the streams the fused kernel did not take: GRU launch, then the streaming delay pass
+        const int64_t r = B - fused, o = fused * T;
+        int rc = ntm_gru_forward(w_ih, w_hh, b_ih, b_hh, w_o, nullptr, H, x + o, pre_d + o, r, T, T, T,
+                                 h_state ? h_state + fused * H : nullptr, stream);
+        if (rc != NTM_OK) return rc;
+        if (r <= 0 || T <= 0) return NTM_OK;
+        if (!d || !y || (D > 0 && !dl_state)) return fail(NTM_EINVAL, "ntm_delay_forward: null pointer");
+        if (fused == 0) return ntm_delay_forward(pre_d, d, y, B, T, dl_state, D, warmup, err_flag, stream);
+        // mixed: interpolate the remainder here, then ONE buffer update over all streams (it reads the flag both parts raise)
+        hipError_t e = ntm::launch_delay_apply(pre_d + o, d + o, y + o, r, T, dl_state ? dl_state + fused * D : nullptr, D, warmup,
+                                               err_flag, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "ntm_diffdel_gru_forward");
+    }
+    hipError_t e = ntm::launch_delay_update(pre_d, B, T, dl_state, D, err_flag, (hipStream_t)stream);
+    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_diffdel_gru_forward");
+}
+
 int ntm_diffdel_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
                             const float *w_o, int H, const float *x, const float *d, float *y, float *pre_d,
                             int64_t B, int64_t T, float *h_state, float *dl_state, int D, int warmup,
                             int32_t *err_flag, void *stream)
 {
-    if (!pre_d || pre_d == y) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: pre_d must be a distinct buffer");
-    int rc = ntm_gru_forward(w_ih, w_hh, b_ih, b_hh, w_o, nullptr, H, x, pre_d, B, T, T, T, h_state, stream);
-    if (rc != NTM_OK) return rc;
-    return ntm_delay_forward(pre_d, d, y, B, T, dl_state, D, warmup, err_flag, stream);
+    return ntm_diffdel_gru_forward_ex(w_ih, w_hh, b_ih, b_hh, w_o, H, x, d, y, pre_d, B, T, h_state, dl_state, D, warmup,
+                                      err_flag, NTM_DIFFDEL_AUTO, stream);
 }
 
 int ntm_esr_splits(int64_t B, int64_t T, int64_t skip) { return ntm::esr_default_splits(B, T, skip); }

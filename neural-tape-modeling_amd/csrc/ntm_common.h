@@ -34,6 +34,13 @@ struct GruArgs {
     unsigned long long *dbg;  // diagnostic stamp sums (ntm_debug_gru_stamps), else null
     int abl;                  // diagnostic ablation mask (ntm_debug_gru_ablate), else 0
     int engine;               // MFMA2 GEMV engine: 0 exact fp32, 1 split-fp16 x3 (NTM_GRU_F16X3)
+    // fused DiffDelRNN step (gru_mfma2_kernel<FUSE>): `y` above is then pre_d, and the delay line writes yd
+    const float *dd = nullptr;      // delay trajectory [B,T] in samples, contiguous
+    float *yd = nullptr;            // delayed output [B,T], contiguous
+    const float *dl_buf = nullptr;  // carried delay buffer [B,D] (read only here; delay_update_kernel moves it on)
+    int32_t *dl_flag = nullptr;     // sticky range-violation flag (may be null)
+    int D = 0;
+    int warmup = 0;
 };
 
 }  // namespace ntm
@@ -52,6 +59,7 @@ inline int device_cus()
 hipError_t launch_gru_mfma(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_valu(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream);
+hipError_t launch_gru_mfma2_fused(const GruArgs &a, hipStream_t stream);   // GRU + head + delay line in one launch
 hipError_t launch_gru_mfma3(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_lat(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_mfma4(const GruArgs &a, hipStream_t stream);

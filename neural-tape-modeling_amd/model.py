@@ -363,14 +363,25 @@ class DiffDelRNN(_GRUHead):
         self.hidden = self.hidden.clone().detach()
         self.diffdel.detach_buffer()
 
+    # "auto": ONE launch for the whole step where the matrix-pipe kernel runs (the delay line fused into the GRU
+    # kernel's output flush, include/ntm.h ntm_diffdel_gru_forward), GRU launch + streaming delay pass elsewhere;
+    # "two_pass" / "fused" force either form (A/B measurements, tests).  A laboratory or explicitly chosen GRU kernel
+    # (`kernel_variant` other than "auto") and `skip=True` (pre_d = GRU(x) + x sits between the two) take the two calls.
+    delay_mode = "auto"
+
     @torch.no_grad()
     def forward(self, x, del_traj, warmup=False, _events=None):
         """(x, del_traj) (N,1,T) -> (y, pre_d) (code/model.py:393-424).  `_events`: three torch.cuda.Event objects
-        recorded before the GRU launch, between it and the delay pass, and after (bench.py's per-kernel timing)."""
+        recorded before the GRU launch, between it and the delay pass, and after (bench.py's per-kernel timing; with the
+        fused step the middle one is recorded right behind the fused launch, ahead of the buffer update)."""
         xbt = _as_bt(x, "DiffDelRNN.forward")
         dbt = _as_bt(del_traj, "DiffDelRNN.forward")
         if dbt.shape != xbt.shape:
             raise RuntimeError(f"shape mismatch: x {tuple(x.shape)} vs del_traj {tuple(del_traj.shape)}")
+        B, T = xbt.shape
+        if self.kernel_variant == "auto" and not self.skip and self.delay_mode != "two_pass":
+            y, pre = self._fused_step(xbt, dbt, warmup, _events)
+            return y.view(B, 1, T), pre.view(B, 1, T)
         if _events:
             _events[0].record()
         pre = self._gru(xbt)
@@ -381,8 +392,41 @@ class DiffDelRNN(_GRUHead):
         y = self.diffdel._run(pre, dbt, warmup)
         if _events:
             _events[2].record()
-        B, T = xbt.shape
         return y.view(B, 1, T), pre.view(B, 1, T)
+
+    def _fused_step(self, xbt, dbt, warmup, _events=None):
+        """One C-ABI call for GRU + head + delay line (ntm_diffdel_gru_forward_ex); carries self.hidden and the delay
+        buffer exactly as the two calls do."""
+        B, T = xbt.shape
+        dl = self.diffdel
+        D = int(dl.max_delay)
+        _require_hip(self.GRU.weight_hh_l0, "model parameters (call .to('cuda'))")
+        if dl.buffer.shape[0] != B or dl.buffer.shape[2] != D:
+            raise RuntimeError(f"Sizes of tensors must match: buffer {list(dl.buffer.shape)} vs input batch {B}")
+        if dl.buffer.device != xbt.device or dl.buffer.dtype != torch.float32 or not dl.buffer.is_contiguous():
+            dl.buffer = dl.buffer.to(device=xbt.device, dtype=torch.float32).contiguous()
+        if dl._err is None or dl._err.device != xbt.device:
+            dl._err = torch.zeros(1, device=xbt.device, dtype=torch.int32)
+        h = self._hidden_for(B, xbt.device)
+        y, pre = torch.empty_like(xbt), torch.empty_like(xbt)
+        dl._fresh = False
+        g = self.GRU
+        if _events:
+            _events[0].record()
+        rc = _lib.lib().ntm_diffdel_gru_forward_ex(
+            ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0), ptr(self.output.weight),
+            self.hidden_size, ptr(xbt), ptr(dbt), ptr(y), ptr(pre), B, T, ptr(h), ptr(dl.buffer), D, int(bool(warmup)),
+            ptr(dl._err), _lib.DIFFDEL_MODES[self.delay_mode], _lib.current_stream())
+        _lib.check(rc, "ntm_diffdel_gru_forward")
+        if _events:
+            _events[1].record()
+            _events[2].record()
+        self.hidden = h
+        if not dl.defer_check:
+            dl.raise_if_violated()
+        else:
+            dl._unchecked = True
+        return y, pre
 
     @torch.no_grad()
     def predict(self, input, d_traj, segment_length=None, _events=None):

@@ -173,14 +173,28 @@ def test_warm_start_cache_is_bit_identical_and_follows_the_parameters(ntm):
 
 
 # ----------------------------------------------------------------------------- ntm_diffdel_gru_forward through raw ctypes
+_DD_MODE = [None]      # None: ntm_diffdel_gru_forward; else the mode argument of ntm_diffdel_gru_forward_ex
+
+
 def _dd_call(L, w, x, d, y, pre, h, buf, D, flag, warmup=0):
     B, T = x.shape
-    return L.ntm_diffdel_gru_forward(p(w["GRU.weight_ih_l0"]), p(w["GRU.weight_hh_l0"]), p(w["GRU.bias_ih_l0"]),
-                                     p(w["GRU.bias_hh_l0"]), p(w["output.weight"]), 64, p(x), p(d), p(y), p(pre), B, T,
-                                     p(h), p(buf), D, warmup, p(flag), None)
+    args = [p(w["GRU.weight_ih_l0"]), p(w["GRU.weight_hh_l0"]), p(w["GRU.bias_ih_l0"]), p(w["GRU.bias_hh_l0"]),
+            p(w["output.weight"]), 64, p(x), p(d), p(y), p(pre), B, T, p(h), p(buf), D, warmup, p(flag)]
+    if _DD_MODE[0] is None:
+        return L.ntm_diffdel_gru_forward(*args, None)
+    return L.ntm_diffdel_gru_forward_ex(*args, _DD_MODE[0], None)
 
 
-def test_diffdel_entry_point_raw_ctypes(ntm):
+@pytest.mark.parametrize("mode", [None, 1, 2])
+def test_diffdel_entry_point_raw_ctypes(ntm, mode):
+    _DD_MODE[0] = mode
+    try:
+        _diffdel_entry_point_raw_ctypes(ntm)
+    finally:
+        _DD_MODE[0] = None
+
+
+def _diffdel_entry_point_raw_ctypes(ntm):
     """include/ntm.h `ntm_diffdel_gru_forward` (replaces DiffDelRNN.forward, code/model.py:393-424) called directly:
     golden g5 (the reference's predict = warm-up call + forward), the oracle on a ragged batch, chunked == one-shot,
     warm-up mode, the refusal of pre_d == y, and a delay beyond D (sticky flag, dl_state untouched, later calls no-ops
@@ -364,3 +378,168 @@ def test_bench_line_carries_the_other_workloads():
     assert ow["diffdel"]["bytes_per_sample"] == 16 and "1040 segments x 4096" in ow["diffdel"]["workload"]
     assert "2048 segments x 4096" in ow["gru_B2048"]["workload"]
     assert out["metric"].startswith("audio samples/sec") and out["cpu_baseline"]["value"] > 0 and out["checks"]["streams_vs_oracle"]["max_abs"] < TOL
+
+
+# ----------------------------------------------------------------------------- the fused DiffDelRNN step
+def _ddr(ntm, max_delay, mode):
+    m = ntm.DiffDelRNN(1, 64, 1, max_delay=max_delay)
+    m.load_state_dict(ntm.weights.load_state_dict(W_D))
+    m = m.to("cuda").eval()
+    m.delay_mode = mode
+    return m
+
+
+def _trajectories(rng, B, T, D):
+    """Delay trajectories that reach every branch of the fused pass: slow wow (one 8-sample window per thread), white
+    (general form), constant integer parts, a ramp through every integer part up to D itself, negative delays, delays so
+    small that the taps are the newest samples (read back right behind the store), steps of exactly 3 and of 4 in the
+    integer part inside one 4-sample group."""
+    n = np.arange(T)
+    d = np.empty((B, T), np.float32)
+    for b in range(B):
+        k = b % 8
+        if k == 0:
+            d[b] = 0.6 * D + 0.3 * D * np.sin(2 * np.pi * n / rng.uniform(500, 3000) + rng.uniform(0, 6))
+        elif k == 1:
+            d[b] = rng.uniform(0, D, T)
+        elif k == 2:
+            d[b] = np.floor(0.5 * D) + (n % 2) * 0.999
+        elif k == 3:
+            d[b] = np.clip(n.astype(np.float64) * D / max(T - 1, 1), 0, D)
+            d[b, -1] = D
+        elif k == 4:
+            d[b] = np.where(n % 97 == 0, -0.5, 0.25 * D)
+        elif k == 5:
+            d[b] = np.abs(1.5 * np.sin(n / 7.0)) + (0 if D < 3 else 0.25 * ((n // 64) % 3))      # taps = the newest samples
+        elif k == 6:
+            d[b] = np.minimum(D, 5 + 3.0 * (n % 4 == 3) + 0.5)                                   # span 3 inside a group
+        else:
+            d[b] = np.minimum(D, 5 + 4.0 * (n % 4 == 2) + 0.25)                                  # span 4: general form
+    return np.clip(d, -0.9, D).astype(np.float32)
+
+
+@pytest.mark.parametrize("B,T,D", [(1, 1, 37), (5, 7, 37), (16, 63, 5), (17, 64, 37), (33, 65, 301), (8, 127, 37), (40, 130, 64),
+                                   (19, 200, 301), (24, 1000, 37), (37, 2500, 301), (9, 4099, 1847), (64, 4096, 1847),
+                                   (300, 1500, 128), (16, 3000, 1), (16, 997, 3)])
+def test_fused_diffdel_step_equals_the_two_pass_step_bit_for_bit(ntm, B, T, D):
+    """The delay line fused into the GRU kernel (ntm_diffdel_gru_forward, NTM_DIFFDEL_FUSED) against the GRU launch +
+    streaming delay pass (NTM_DIFFDEL_TWO_PASS) on the same inputs and carried state: pre_d, y, hidden state and
+    delay buffer bit for bit -- ragged batches and lengths (T % 4 != 0 takes the unaligned stores), T shorter than a
+    tile / than the delay line, history taps out of a random carried buffer, every trajectory class; then chunked ==
+    one-shot for the fused form, and y against the oracle's delay line on the GPU's own pre_d."""
+    rng = np.random.default_rng(B * 100003 + T * 17 + D)
+    x = rng.uniform(-0.5, 0.5, (B, T)).astype(np.float32)
+    d = _trajectories(rng, B, T, D)
+    h0 = rng.uniform(-0.3, 0.3, (B, 64)).astype(np.float32)
+    b0 = rng.uniform(-0.3, 0.3, (B, D)).astype(np.float32)
+    res = {}
+    for mode in ("two_pass", "fused"):
+        m = _ddr(ntm, D - 1, mode)
+        if mode == "two_pass":
+            m.kernel_variant = "mfma2"      # the same GRU kernel as the fused step ("auto" would pick the low-latency one here)
+        m.initialize_hidden(B, D - 1)
+        m.hidden, m.diffdel.buffer = dev(h0).view(1, B, 64), dev(b0).view(B, 1, D)
+        y, pre = m(dev(x).unsqueeze(1), dev(d).unsqueeze(1))
+        res[mode] = (y[:, 0].clone(), pre[:, 0].clone(), m.hidden.clone(), m.diffdel.buffer.clone())
+    for a, b, what in zip(res["two_pass"], res["fused"], ("y", "pre_d", "hidden", "buffer")):
+        assert torch.equal(a, b), f"{what}: max |diff| {float((a - b).abs().max())}"
+    y, pre, h, buf = (t.cpu().numpy() for t in res["fused"])
+    yo, bo = oracle.delay_forward(pre, d, b0)
+    assert np.array_equal(y, yo) and np.array_equal(buf[:, 0], bo)
+    if T >= 3:
+        m = _ddr(ntm, D - 1, "fused")
+        m.initialize_hidden(B, D - 1)
+        m.hidden, m.diffdel.buffer = dev(h0).view(1, B, 64), dev(b0).view(B, 1, D)
+        cuts = sorted({0, T // 3, min(T, T // 3 + 70), T})
+        ys = [m(dev(x[:, c0:c1]).unsqueeze(1), dev(d[:, c0:c1]).unsqueeze(1))[0] for c0, c1 in zip(cuts[:-1], cuts[1:]) if c1 > c0]
+        assert torch.equal(torch.cat(ys, 2)[:, 0], res["fused"][0])
+        assert torch.equal(m.hidden, res["fused"][2]) and torch.equal(m.diffdel.buffer, res["fused"][3])
+
+
+def test_fused_diffdel_step_warmup_violation_and_predict(ntm):
+    """Fused form: warm-up mode (y = pre_d, buffer filled), a delay beyond D (AssertionError, delay state untouched,
+    hidden moved on -- as the two-pass form and the reference), the deferred check of predict(), golden g5 and g8."""
+    rng = np.random.default_rng(77)
+    B, T, D = 21, 700, 301
+    x = dev(rng.uniform(-0.5, 0.5, (B, 1, T)).astype(np.float32))
+    d_np = _trajectories(rng, B, T, D)
+    out = {}
+    for mode in ("two_pass", "fused"):
+        m = _ddr(ntm, D - 1, mode)
+        if mode == "two_pass":
+            m.kernel_variant = "mfma2"
+        m.initialize_hidden(B, D - 1)
+        yw, pw = m(x, dev(d_np).unsqueeze(1), warmup=True)
+        assert torch.equal(yw, pw)
+        y2, p2 = m(x, dev(d_np).unsqueeze(1))
+        bad = d_np.copy()
+        bad[3, 500] = D + 0.5
+        buf_before, h_before = m.diffdel.buffer.clone(), m.hidden.clone()
+        with pytest.raises(AssertionError):
+            m(x, dev(bad).unsqueeze(1))
+        assert torch.equal(m.diffdel.buffer, buf_before) and not torch.equal(m.hidden, h_before)
+        y3, _ = m(x, dev(d_np).unsqueeze(1))                            # usable again after the raise
+        out[mode] = (yw, y2, y3, m.hidden.clone(), m.diffdel.buffer.clone())
+    for a, b in zip(out["two_pass"], out["fused"]):
+        assert torch.equal(a, b)
+    g = load("g5_diffdel_predict.npz")
+    m = _ddr(ntm, int(g["max_delay"]), "fused")
+    y, pre = m.predict(dev(g["x"]), dev(g["d"]))
+    assert np.abs(pre.cpu().numpy() - g["pre_d"]).max() < TOL and np.abs(y.cpu().numpy() - g["y"]).max() < TOL
+    assert np.abs(m.diffdel.buffer.cpu().numpy() - g["buffer"]).max() < TOL and np.abs(m.hidden.cpu().numpy() - g["hidden"]).max() < TOL
+    bad = g["d"].copy()
+    bad[0, 0, 4000] = int(g["D_effective"]) + 1.0
+    with pytest.raises(AssertionError):
+        m.predict(dev(g["x"]), dev(bad))
+    g8 = load("g8_diffdel_batched.npz")
+    m = _ddr(ntm, int(g8["max_delay"]), "fused")
+    xb, db = dev(g8["x"]), dev(g8["d"])
+    init, chunk = int(g8["init_len"]), int(g8["chunk"])
+    m.initialize_hidden(xb.shape[0], m.max_delay)
+    ys, ps = [], []
+    yy, pp = m(xb[:, :, :init], db[:, :, :init], warmup=True)
+    ys.append(yy); ps.append(pp)
+    for c0 in range(init, xb.shape[2], chunk):
+        yy, pp = m(xb[:, :, c0:c0 + chunk], db[:, :, c0:c0 + chunk])
+        ys.append(yy); ps.append(pp)
+    assert np.abs(torch.cat(ys, 2).cpu().numpy() - g8["y"]).max() < TOL and np.abs(torch.cat(ps, 2).cpu().numpy() - g8["pre_d"]).max() < TOL
+    assert np.abs(m.diffdel.buffer.cpu().numpy() - g8["buffer"]).max() < TOL
+
+
+FULL = pytest.mark.skipif(os.environ.get("NTM_SKIP_FULL") == "1", reason="full 4096x65536 pass skipped on request")
+
+
+@FULL
+def test_fused_diffdel_full_size_equals_two_pass_and_oracle(ntm):
+    """BASELINE configs[2] at full size (4096 distinct streams x 65 536 samples, D = 1847, the bench's trajectories): the
+    fused launch (what `auto` picks here) against the two-pass step over the WHOLE batch bit for bit, scattered streams
+    against the oracle, and a batch with a remainder (4096 + 40 streams: fused kernel + low-latency kernel + streaming pass
+    + one buffer update)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    B, T = 4096, 65536
+    devc = torch.device("cuda", 0)
+    x = bench.synth_input(B, T, devc, seed=1234)
+    ma = ntm.harness.build_model(W_D, max_delay_seconds=0.0335)
+    d = bench.delay_trajectories(B, T, devc, ma.max_delay)
+    assert ma.delay_mode == "auto"
+    ya, pa = ma.predict(x, d)
+    ha, ba = ma.hidden.clone(), ma.diffdel.buffer.clone()
+    mt = ntm.harness.build_model(W_D, max_delay_seconds=0.0335)
+    mt.delay_mode = "two_pass"
+    yt, pt = mt.predict(x, d)
+    assert torch.equal(pa, pt) and torch.equal(ya, yt) and torch.equal(ha, mt.hidden) and torch.equal(ba, mt.diffdel.buffer)
+    del yt, pt
+    rows = [0, 15, 16, 2047, 2048, 4095]
+    yo, po, ho, bo = oracle.diffdel_predict(oracle_weights(W_D), x[rows, 0].cpu().numpy(), d[rows, 0].cpu().numpy(), ma.max_delay, threads=8)
+    assert np.abs(pa[rows, 0].cpu().numpy() - po).max() < TOL and np.abs(ya[rows, 0].cpu().numpy() - yo).max() < TOL
+    assert np.abs(ba[rows, 0].cpu().numpy() - bo).max() < TOL
+    del ya, pa
+    # remainder: B = one device round of the matrix-pipe kernel + 40 streams
+    Br, Tr = 4096 + 40, 4096
+    xr, dr = x[:, :, :Tr].contiguous(), d[:, :, :Tr].contiguous()
+    xr = torch.cat([xr, xr[:40] * 0.5], 0)
+    dr = torch.cat([dr, dr[100:140]], 0)
+    y1, p1 = ma.predict(xr, dr)
+    y2, p2 = mt.predict(xr, dr)
+    assert y1.shape[0] == Br and torch.equal(y1, y2) and torch.equal(p1, p2) and torch.equal(ma.diffdel.buffer, mt.diffdel.buffer)
