@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         const int64_t gs = s0 + (tid >> 4), gt = tile * TT + 4 * (tid & 15);
         if (gs < a.B) {
             float *dst = a.y + gs * a.ys + gt;
-            if (y_vec_ok && gt + 3 < T) {
+            if (__builtin_expect(y_vec_ok && gt + 3 < T, 1)) {
                 *(f32x4 *)dst = v;
             } else {
 #pragma unroll
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
                     if (gt + c < T) dst[c] = v[c];
             }
             if constexpr (FUSE) {
-                if (a.warmup) {          // warm-up mode: the delay line passes pre_d through (code/model.py:288-292)
+                if (__builtin_expect(a.warmup != 0, 0)) {          // warm-up mode: the delay line passes pre_d through (code/model.py:288-292)
                     float *dw = a.yd + gs * T + gt;
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         dl_out_gt = gt;
         dl_out_full = dl_row && (WHOLE || gt + 3 < dl_T);
         const bool gen = dl_row && (WHOLE || gt < dl_T) && !dl_fast;
-        if (__any(gen)) {
+        if (__builtin_expect(__any(gen), 0)) {
             // rare (never under wow and flutter once n > k): history taps, k = D, d < 0, NaN, d > D, and the ragged tail of
             // a row, whose delays are fetched and whose outputs are stored right here
             if (gen)
@@ -522,22 +522,22 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
                     // keeps "a load into these registers may be pending" alive around the loop and drains the VM counter
                     // in front of the NEXT loads -- the x tile fetched just before them, a full memory round trip.
                     __builtin_amdgcn_s_waitcnt(0x0F70);
-                    if (dl_stage == 2) dl_compute(std::bool_constant<(HK > 0)>{});
+                    if (__builtin_expect(dl_stage == 2, 1)) dl_compute(std::bool_constant<(HK > 0)>{});
                 }
                 // the x loads go out before the flush's stores (no VMEM drain between them)
-                if ((tile + 1) * TT < T) load_x_tile(tile + 1, xr);
+                if (__builtin_expect((tile + 1) * TT < T, 1)) load_x_tile(tile + 1, xr);
                 if constexpr (FUSE) {
-                    if (dl_on && t > 65) dl_load_d((int)next_flush, std::bool_constant<(HK > 0)>{});
+                    if (__builtin_expect(dl_on && t > 65, 1)) dl_load_d((int)next_flush, std::bool_constant<(HK > 0)>{});
                     dl_store();
                 }
-                if (t > 65) { flush_y_tile(next_flush); ++next_flush; }
+                if (__builtin_expect(t > 65, 1)) { flush_y_tile(next_flush); ++next_flush; }
             } else if (HK == 2 || (HK < 0 && ph == 34)) {
-                if ((tile + 1) * TT < T) store_x_tile(tile + 1, xr);
+                if (__builtin_expect((tile + 1) * TT < T, 1)) store_x_tile(tile + 1, xr);
                 // FUSE: this thread's pre_d stores of phase 2 have completed; step 35's barrier makes that true of the
                 // whole workgroup before phase 36 reads them back
                 if constexpr (FUSE) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), as a MachineInstr hipcc accounts for
             } else if (FUSE && (HK == 3 || (HK < 0 && ph == 36))) {
-                if (dl_stage == 1) dl_issue_taps(std::bool_constant<(HK > 0)>{});
+                if (__builtin_expect(dl_stage == 1, 1)) dl_issue_taps(std::bool_constant<(HK > 0)>{});
             }
         }
 
