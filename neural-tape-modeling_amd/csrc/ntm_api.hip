@@ -155,7 +155,8 @@ int ntm_diffdel_gru_forward_ex(const float *w_ih, const float *w_hh, const float
         if (T == 0) return NTM_OK;
         if (!w_ih || !w_hh || !b_ih || !b_hh || !w_o || !x || !d || !y || (D > 0 && !dl_state))
             return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: null pointer");
-        if (x == y || x == pre_d) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: outputs must not alias x");
+        if (x == y || x == pre_d || d == y || d == pre_d)
+            return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: outputs must not alias x or d");
         ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, nullptr, x, pre_d, h_state, fused, T, T, T, nullptr, 0, 0};
         a.dd = d;
         a.yd = y;

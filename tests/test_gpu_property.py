@@ -191,3 +191,48 @@ def test_diffdel_predict_random_batches_and_trajectories(ntm, B, T, delay_s, wow
     if chunk is not None:
         y1, pre1 = m.predict(dev(x).unsqueeze(1), dev(d).unsqueeze(1))
         assert torch.equal(y, y1) and torch.equal(pre, pre1)
+
+
+# ----------------------------------------------------------------------------- the fused DiffDelRNN step (round 3)
+@settings(max_examples=60, **SET)
+@given(B=st.integers(1, 40), T=st.integers(1, 700), D=st.integers(1, 400), seed=st.integers(0, 2**31 - 1),
+       cuts=st.lists(st.integers(1, 699), max_size=3), kind=st.sampled_from(["wow", "white", "integer", "tiny", "mixed"]))
+def test_fused_diffdel_step_random_shapes_bit_identical_to_two_pass(ntm, B, T, D, seed, cuts, kind):
+    """ntm_diffdel_gru_forward: the delay line fused into the GRU kernel (NTM_DIFFDEL_FUSED) against the GRU launch +
+    streaming pass (NTM_DIFFDEL_TWO_PASS, same GRU kernel) on random batches, lengths (T < 64, T < D, T % 4 != 0), delay-line
+    lengths, carried state and chunkings: pre_d, y, hidden state and delay buffer bit for bit; y also equals the oracle's
+    delay line on the GPU's own pre_d."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-0.5, 0.5, (B, T)).astype(np.float32)
+    n = np.arange(T)
+    if kind == "wow":
+        d = 0.5 * D + 0.45 * D * np.sin(2 * np.pi * n[None, :] / rng.uniform(20, 900, (B, 1)) + rng.uniform(0, 6, (B, 1)))
+    elif kind == "white":
+        d = rng.uniform(-0.9, D, (B, T))
+    elif kind == "integer":
+        d = np.round(rng.uniform(0, D, (B, T)))
+    elif kind == "tiny":
+        d = np.abs(2.5 * np.sin(n[None, :] / rng.uniform(3, 30, (B, 1))))
+    else:
+        d = np.where(rng.uniform(size=(B, T)) < 0.05, rng.uniform(-0.9, D, (B, T)), 0.3 * D + 0.1 * n[None, :] % max(D * 0.6, 1))
+    d = np.clip(d, -0.9, D).astype(np.float32)
+    d[rng.integers(0, B), rng.integers(0, T)] = D
+    h0 = rng.uniform(-0.3, 0.3, (B, 64)).astype(np.float32)
+    b0 = rng.uniform(-0.3, 0.3, (B, D)).astype(np.float32)
+    edges = [0] + sorted({c for c in cuts if c < T}) + [T]
+    res = {}
+    for mode in ("two_pass", "fused"):
+        m = ntm.DiffDelRNN(1, 64, 1, max_delay=D - 1)
+        m.load_state_dict(ntm.weights.load_state_dict(ntm.weights.W_DIFFDEL))
+        m = m.to("cuda").eval()
+        m.delay_mode = mode
+        if mode == "two_pass":
+            m.kernel_variant = "mfma2"
+        m.initialize_hidden(B, D - 1)
+        m.hidden, m.diffdel.buffer = dev(h0).view(1, B, 64), dev(b0).view(B, 1, D)
+        outs = [m(dev(x[:, a:b]).unsqueeze(1), dev(d[:, a:b]).unsqueeze(1)) for a, b in zip(edges, edges[1:])]
+        res[mode] = (torch.cat([o[0] for o in outs], 2)[:, 0], torch.cat([o[1] for o in outs], 2)[:, 0], m.hidden.clone(), m.diffdel.buffer.clone())
+    for a, b, what in zip(res["two_pass"], res["fused"], ("y", "pre_d", "hidden", "buffer")):
+        assert torch.equal(a, b), what
+    yo, bo = oracle.delay_forward(res["fused"][1].cpu().numpy(), d, b0)
+    assert np.array_equal(res["fused"][0].cpu().numpy(), yo) and np.array_equal(res["fused"][3][:, 0].cpu().numpy(), bo)

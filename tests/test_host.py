@@ -190,3 +190,17 @@ def test_recorded_bench_line_follows_the_contract():
     assert abs(d["value"] - seg * T / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert r["kernel_ms"] <= d["ms_per_step"]
     assert abs(r["achieved"] - 25088.0 * seg * T / d["n_gpus"] / (r["kernel_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+    # round 3: the BASELINE configs no other driver-run line covers ride along (never part of `value`): configs[2], [3] and
+    # the GRU workload at the per-GPU shapes of configs[4]'s strong-scaling legs, each checked against the oracle
+    ow = d["other_workloads"]
+    assert {"diffdel", "tcn", "gru_B8192", "gru_B16384", "gru_B32768"} <= set(ow) and "not a scaling curve" in ow["note"]
+    for k, v in ow.items():
+        if k == "note":
+            continue
+        assert v["kernel"] and 0 < v["kernel_ms"] <= v["ms_per_step"] * 1.001 and 0.3 < v["roofline"]["frac"] < 1.0
+        assert v["checks"]["deterministic"] is True and len(v["checks"]["streams_checked"]) == 4
+        assert v["checks"]["vs_oracle_max_abs"] < 1e-5 and v["checks"]["samples_each"] == 65536
+    for b in (8192, 16384, 32768):
+        v = ow[f"gru_B{b}"]
+        flops = 25088.0 * b * 65536
+        assert abs(v["roofline"]["achieved"] - flops / (v["kernel_ms"] * 1e-3) / 1e12) < 1e-6 * v["roofline"]["achieved"]
