@@ -543,3 +543,37 @@ def test_fused_diffdel_full_size_equals_two_pass_and_oracle(ntm):
     y1, p1 = ma.predict(xr, dr)
     y2, p2 = mt.predict(xr, dr)
     assert y1.shape[0] == Br and torch.equal(y1, y2) and torch.equal(p1, p2) and torch.equal(ma.diffdel.buffer, mt.diffdel.buffer)
+
+
+@pytest.mark.parametrize("B,T,D", [(5136, 1000, 301), (8192 + 16, 515, 64)])
+def test_fused_diffdel_step_many_groups_build(ntm, B, T, D):
+    """More stream groups than CUs: the fused step runs the small-LDS build of the kernel (YPN = 4, two workgroups per CU)
+    -- `auto` picks it for these batches (B = one device round + more than 1024 streams).  Against the two-pass step with
+    the same GRU kernel: bit for bit; scattered streams against the oracle."""
+    rng = np.random.default_rng(B + T)
+    x = torch.from_numpy(rng.uniform(-0.5, 0.5, (B, 1, T)).astype(np.float32)).cuda()
+    n = np.arange(T)
+    d_np = np.clip(0.5 * D + 0.45 * D * np.sin(2 * np.pi * n[None, :] / rng.uniform(50, 900, (B, 1)) + rng.uniform(0, 6, (B, 1))), 0, D).astype(np.float32)
+    d_np[:, :8] = rng.uniform(-0.5, D, (B, 8))
+    d = torch.from_numpy(d_np).cuda().unsqueeze(1)
+    h0 = rng.uniform(-0.3, 0.3, (B, 64)).astype(np.float32)
+    b0 = rng.uniform(-0.3, 0.3, (B, D)).astype(np.float32)
+    res = {}
+    for mode in ("two_pass", "auto"):
+        m = _ddr(ntm, D - 1, mode)
+        if mode == "two_pass":
+            m.kernel_variant = "mfma2"
+        m.initialize_hidden(B, D - 1)           # same carried state for both (predict()'s warm-up would come from two
+        m.hidden, m.diffdel.buffer = dev(h0).view(1, B, 64), dev(b0).view(B, 1, D)      # different kernels at B = 1)
+        y, pre = m(x, d)
+        res[mode] = (y, pre, m.hidden.clone(), m.diffdel.buffer.clone())
+    # `auto` gives a remainder of at most 1024 streams behind whole device rounds to the low-latency kernel + the streaming
+    # pass (B = 8208: 8192 fused + 16): those streams agree with the matrix-pipe kernel to rounding, the others bit for bit
+    nf = B if B % 4096 > 1024 or B % 4096 == 0 else (B // 4096) * 4096
+    for a, b, what in zip(res["two_pass"], res["auto"], ("y", "pre_d", "hidden", "buffer")):
+        a, b = (a[0], b[0]) if what == "hidden" else (a, b)
+        assert torch.equal(a[:nf], b[:nf]), what
+        assert nf == B or float((a[nf:] - b[nf:]).abs().max()) < TOL, what
+    rows = [0, 15, 16, 4095, 4096, 4111, B - 1]
+    yo, po, ho, bo = oracle.diffdel_forward(oracle_weights(W_D), x[rows, 0].cpu().numpy(), d_np[rows], h0[rows], b0[rows], threads=4)
+    assert np.abs(res["auto"][1][rows, 0].cpu().numpy() - po).max() < TOL and np.abs(res["auto"][0][rows, 0].cpu().numpy() - yo).max() < TOL
