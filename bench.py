@@ -273,10 +273,13 @@ def other_workloads(a, dev, check):
     out = {"note": "single-GPU measurements beside the headline; gru_B* are the per-GPU shapes of configs[4]'s "
                    "strong-scaling legs (per-GPU legs, not a scaling curve)"}
     threads = _host_threads()
-    for wl in ("diffdel", "tcn"):
-        out[wl] = measure_workload(wl, a.batch, a.samples, a.other_steps, 1, check, dev, threads)
-    for b in a.other_gru_batches:
-        out[f"gru_B{b}"] = measure_workload("gru", b, a.samples, a.other_steps, 1, check, dev, threads)
+    jobs = [(wl, wl, a.batch) for wl in ("diffdel", "tcn")] + [(f"gru_B{b}", "gru", b) for b in a.other_gru_batches]
+    for key, wl, b in jobs:
+        try:
+            out[key] = measure_workload(wl, b, a.samples, a.other_steps, 1, check, dev, threads)
+        except Exception as e:          # a side workload must never take the headline line down with it (e.g. out of memory
+            out[key] = {"error": f"{type(e).__name__}: {e}"[:500]}      # on a box that is shared or smaller than expected)
+            torch.cuda.empty_cache()
     return out
 
 
