@@ -218,7 +218,7 @@ def measure_workload(workload, B, T, steps, warmup, check, dev, threads=1, delay
                                 "delay_pass_hbm": {"achieved": alg / dsec / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                                    "frac": alg / dsec / 1e9 / PEAK_HBM_GBS, "bytes_per_sample": 12},
                                 "identical_output": bool(torch.equal(y2, y))}
-            model.delay_mode = "auto"
+            model.delay_mode = delay_mode
             del y2
         else:
             # K2 as a separate streaming pass: pre_d and d read once, y written once = 12 algorithmic bytes per sample

@@ -345,7 +345,7 @@ class DiffDelRNN(_GRUHead):
         fresh = (self.warm_cache and self.hidden is None and dl._fresh and dl.buffer.shape[0] == 1
                  and dl.buffer.device == dev)
         if fresh:
-            key = self._warm_key(int(dl.max_delay))
+            key = self._warm_key(int(dl.max_delay), self.delay_mode)     # fused / two-pass warm-ups run different GRU kernels at B = 1
             if self._warm is not None and self._warm[0] == key:
                 self.hidden = self._warm[1].clone()
                 dl.buffer = self._warm[2].clone()
