@@ -283,6 +283,48 @@ def other_workloads(a, dev, check):
     return out
 
 
+def live_traffic(kernel_regex=r"gru_mfma2_kernel<true, false, 0, 0, 16, false>"):
+    """HBM bytes per launch of the headline kernel, measured in this run: two child processes
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 2 ...` (separate passes, kernel trace
+    only, the interpreter directly behind `--`: the combination MI355X_MICROARCH.md prescribes), the median over the
+    full-size launches, FETCH_SIZE doubled (gfx950 reports half of a wide coalesced streaming read), KB of 1024 bytes.
+    -> (bytes, source note) or (None, reason)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if prof is None:
+        return None, "rocprofv3 not on the PATH"
+    rx = re.compile(kernel_regex)
+    med = {}
+    try:
+        with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+            for c in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = os.path.join(tmp, c)
+                cmd = [prof, "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
+                       os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--other", "off",
+                       "--traffic", "off"]
+                env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+                env["TMPDIR"] = "/tmp"
+                r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
+                vals = []
+                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    for row in csv.DictReader(open(f)):
+                        if row["Counter_Name"] == c and rx.search(row["Kernel_Name"]):
+                            vals.append(float(row["Counter_Value"]))
+                big = sorted(v for v in vals if v > 0.5 * max(vals)) if vals else []
+                if r.returncode != 0 or not big:
+                    return None, f"{c} pass failed (exit {r.returncode}, {len(vals)} launches seen)"
+                med[c] = big[len(big) // 2]
+    except Exception as e:                                   # a profiler hiccup must never cost the bench line
+        return None, f"{type(e).__name__}: {e}"[:200]
+    return (2.0 * med["FETCH_SIZE"] + med["WRITE_SIZE"]) * 1024.0, (
+        f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes of this command at 2 steps "
+        f"(median of the full-size launches: FETCH {med['FETCH_SIZE']:.0f} KB x 2 (gfx950 correction) + WRITE {med['WRITE_SIZE']:.0f} KB)")
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -413,6 +455,9 @@ def main():
     ap.add_argument("--other", default="auto", choices=["auto", "on", "off"],
                     help="attach `other_workloads` (configs[2], [3] and the per-GPU shapes of configs[4]) to the line: "
                          "auto = only for the default single-GPU workload (4096 x 65536)")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "off"],
+                    help="roofline.traffic of the headline kernel: live = two rocprofv3 --pmc child passes in this run (auto: when "
+                         "rocprofv3 is available), file = the newest profiles/*pmc_traffic_mfma2*.json, off = null")
     ap.add_argument("--delay-mode", default="auto", choices=["auto", "two_pass", "fused"],
                     help="--workload diffdel: the fused DiffDelRNN step (auto: where the matrix-pipe kernel runs) or GRU launch + delay pass")
     ap.add_argument("--other-steps", type=int, default=3)
@@ -601,15 +646,23 @@ def main():
         checks["stream0_vs_reference_max_abs"] = float(np.abs(e).max())
         checks["stream0_vs_reference_esr"] = float((e[INIT_LEN:] ** 2).mean() /
                                                    ((gold["y"][0, 0][INIT_LEN:] ** 2).mean() + ESR_EPS))
-    # HBM bytes per launch from the PMC counters (collected in separate rocprofv3 --pmc passes, gfx950
-    # FETCH_SIZE correction applied; see profiles/*pmc_traffic*.json) -- only for the matching workload
+    # HBM bytes per launch from the PMC counters, collected as MI355X_MICROARCH.md prescribes (separate rocprofv3 --pmc
+    # passes, gfx950 FETCH_SIZE correction) -- only for the matching workload.  `--traffic live` (what `auto` does when
+    # rocprofv3 is on the PATH): the two passes run NOW, as child processes of this line's own command at 2 steps, so the
+    # number belongs to this box and this binary; otherwise, or if a pass fails, the newest profiles/*pmc_traffic*.json.
     traffic, traffic_source = None, None
-    if (B, T) == (4096, 65536) and a.variant in ("auto", "mfma2"):
-        import glob
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic_mfma2*.json")))
-        if files:
-            traffic = json.load(open(files[-1]))["hbm_bytes_per_launch_corrected"]
-            traffic_source = "profiles/" + os.path.basename(files[-1]) + " (rocprofv3 --pmc passes of this command; not re-measured in this run)"
+    if (B, T) == (4096, 65536) and a.variant in ("auto", "mfma2") and a.traffic != "off":
+        profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+        if a.traffic == "live" or (a.traffic == "auto" and world == 1 and not profiled):     # never a profiler inside a profiler
+            traffic, traffic_source = live_traffic()
+        if traffic is None:
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic_mfma2*.json")))
+            if files:
+                why = f"; live passes: {traffic_source}" if traffic_source else ""
+                traffic = json.load(open(files[-1]))["hbm_bytes_per_launch_corrected"]
+                traffic_source = ("profiles/" + os.path.basename(files[-1]) + " (rocprofv3 --pmc passes of this command; not "
+                                  "re-measured in this run" + why + ")")
     out = {
         "metric": "audio samples/sec (44.1 kHz) GRU-HS[64], batch=4096x65536",
         "value": total_samples / elapsed, "unit": "samples/s", "n_gpus": world, "steps": a.steps,

@@ -24,7 +24,7 @@ prof() {   # prof <name> <args...>
 
 for n in $NAMES; do
     case $n in
-        gru)     prof gru bench.py --steps 5 --warmup 2 --no-cpu-baseline ;;
+        gru)     prof gru bench.py --steps 5 --warmup 2 --no-cpu-baseline --traffic file ;;
         diffdel) prof diffdel bench.py --workload diffdel --steps 5 --warmup 2 --no-cpu-baseline ;;
         tcn)     prof tcn bench.py --workload tcn --steps 3 --warmup 1 --no-cpu-baseline ;;
         tape)    prof tape tools/tape_probe.py ;;
