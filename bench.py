@@ -205,6 +205,14 @@ def measure_workload(workload, B, T, steps, warmup, check, dev, threads=1, delay
             # the streaming delay pass: 12 more bytes per sample) is timed beside it for the A/B.
             roof["kernel"] = kernel = "gru_mfma2_kernel<FUSE: GRU + head + delay line> (+ delay_update_kernel)"
             roof["hbm_bytes_per_sample"] = 16
+            if (B, T) == (4096, 65536):          # PMC traffic of the fused kernel (tools/pmc_traffic.sh passes)
+                import glob
+                files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic_diffdel_fused*.json")))
+                if files:
+                    roof["traffic"] = json.load(open(files[-1]))["hbm_bytes_per_launch_corrected"]
+                    roof["traffic_source"] = ("profiles/" + os.path.basename(files[-1]) + " (rocprofv3 --pmc passes of `bench.py "
+                                              "--workload diffdel`; not re-measured in this run; 1.25 x the algorithmic bytes: "
+                                              "the taps come back from beyond L2)")
             model.delay_mode = "two_pass"
             t1, g1, d1 = [], [], []
             for i in range(1 + steps):
