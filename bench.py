@@ -316,7 +316,7 @@ def live_traffic(kernel_regex=r"gru_mfma2_kernel<true, false, 0, 0, 16, false>")
                        "--traffic", "off"]
                 env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
                 env["TMPDIR"] = "/tmp"
-                r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=240)
+                r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
                 vals = []
                 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                     for row in csv.DictReader(open(f)):
