@@ -7,7 +7,9 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 import bench, ntm_amd
 from ntm_amd import weights, _lib
 L = _lib.lib()
-B, T, D = 4096, 65536, 1847
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+D = 1847
 dev = torch.device("cuda", 0)
 x = bench.synth_input(B, T, dev, 1234)[:, 0].contiguous()
 w = {k: v.cuda() for k, v in weights.load_state_dict(weights.W_DIFFDEL).items()}
