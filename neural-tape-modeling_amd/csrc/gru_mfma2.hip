@@ -36,6 +36,9 @@ namespace ntm {
 #ifndef NTM2_NB
 #define NTM2_NB 1
 #endif
+#ifndef NTM2_HKTRIM
+#define NTM2_HKTRIM 1     // whole-tile forms of the x-tile load and the y-tile flush in the unrolled loop (0: the general forms everywhere)
+#endif
 #ifndef NTM2_ORDER
 #define NTM2_ORDER 0      // order of the three accumulator chains inside a K-step: 0 = r, n, z   1 = r, z, n
 #endif
@@ -237,6 +240,22 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
             xr[c] = (st < a.B && tt < T) ? a.x[st * a.xs + tt] : 0.0f;
         }
     };
+#if NTM2_HKTRIM
+    // The same loads for a tile that lies entirely inside [0, T): no bound on the sample index, row pointers computed
+    // once (an absent stream reads the workgroup's first row: its column of the batch is never stored).  At one wave per
+    // SIMD every instruction of a housekeeping step costs the recurrence ~4.5 cycles, a taken branch ~20.
+    const float *xrow[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int e = tid + 256 * c;
+        const int64_t st = s0 + (e >> 6);
+        xrow[c] = a.x + (st < a.B ? st : s0) * a.xs + (e & 63);
+    }
+    auto load_x_tile_whole = [&](int64_t tile, float (&xr)[4]) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) xr[c] = xrow[c][tile * TT];
+    };
+#endif
     auto store_x_tile = [&](int64_t tile, const float (&xr)[4]) {
         float *dst = xb + (tile & 1) * SG * XS;
 #pragma unroll
@@ -248,11 +267,27 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     // y tile flush: thread -> stream tid>>4, samples 4*(tid&15)..+3; the 16 partial planes (wave, lane
     // group) are summed in a fixed order (deterministic), one ds_read_b128 per plane.
     const bool y_vec_ok = ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0) && ((a.ys & 3) == 0);
-    auto flush_y_tile = [&](int64_t tile) {
+    typedef float f32x4y __attribute__((ext_vector_type(4), aligned(4)));     // 16-byte store at 4-byte alignment
+    const bool y_row_ok = (s0 + (tid >> 4)) < a.B;
+    float *const y_row = a.y + (y_row_ok ? s0 + (tid >> 4) : s0) * a.ys + 4 * (tid & 15);
+    (void)y_row;
+    auto flush_y_tile = [&](int64_t tile, auto whole_c) {
+        constexpr bool WHOLE = decltype(whole_c)::value && NTM2_HKTRIM;
         const float *src = yp + (tile & 1) * YPN * YP_Q + (tid >> 4) * YS + 4 * (tid & 15);
         f32x4 v = {bo, bo, bo, bo};
 #pragma unroll
         for (int pl = 0; pl < YPN; ++pl) v += *(const f32x4 *)(src + pl * YP_Q);
+        if constexpr (WHOLE) {
+            // a tile that lies entirely inside [0, T): one predicated 16-byte store (any alignment), nothing else
+            if (y_row_ok) {
+                *(f32x4y *)(y_row + tile * TT) = v;
+                if constexpr (FUSE) {
+                    if (__builtin_expect(a.warmup != 0, 0))      // warm-up mode: the delay line passes pre_d through
+                        *(f32x4y *)(a.yd + (s0 + (tid >> 4)) * T + 4 * (tid & 15) + tile * TT) = v;
+                }
+            }
+            return;
+        }
         const int64_t gs = s0 + (tid >> 4), gt = tile * TT + 4 * (tid & 15);
         if (gs < a.B) {
             float *dst = a.y + gs * a.ys + gt;
@@ -525,12 +560,17 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
                     if (__builtin_expect(dl_stage == 2, 1)) dl_compute(std::bool_constant<(HK > 0)>{});
                 }
                 // the x loads go out before the flush's stores (no VMEM drain between them)
+#if NTM2_HKTRIM
+                if (__builtin_expect((tile + 2) * TT <= T, 1)) load_x_tile_whole(tile + 1, xr);
+                else if ((tile + 1) * TT < T) load_x_tile(tile + 1, xr);
+#else
                 if (__builtin_expect((tile + 1) * TT < T, 1)) load_x_tile(tile + 1, xr);
+#endif
                 if constexpr (FUSE) {
                     if (__builtin_expect(dl_on && t > 65, 1)) dl_load_d((int)next_flush, std::bool_constant<(HK > 0)>{});
                     dl_store();
                 }
-                if (__builtin_expect(t > 65, 1)) { flush_y_tile(next_flush); ++next_flush; }
+                if (__builtin_expect(t > 65, 1)) { flush_y_tile(next_flush, std::bool_constant<(HK > 0)>{}); ++next_flush; }
             } else if (HK == 2 || (HK < 0 && ph == 34)) {
                 if (__builtin_expect((tile + 1) * TT < T, 1)) store_x_tile(tile + 1, xr);
                 // FUSE: this thread's pre_d stores of phase 2 have completed; step 35's barrier makes that true of the
@@ -652,7 +692,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 
     // ---- epilogue: remaining y tiles, final state ---------------------------------------------------
     __syncthreads();
-    while (next_flush * TT < T) { flush_y_tile(next_flush); ++next_flush; }
+    while (next_flush * TT < T) { flush_y_tile(next_flush, std::false_type{}); ++next_flush; }
     if constexpr (FUSE) {
         if (dl_on) {
             // every pre_d tile is stored: make the stores visible to the workgroup, then run the delay tiles that are left
