@@ -5,8 +5,9 @@ N x 4096 segments, sharded by stream, one RCCL all-reduce of the ESR scalars).
 
 A "step" = one pass of the hot path over the rank's batch, inputs resident in HBM:
     warm-start state (1024 zero samples, B=1: a pure function of the weights, computed by the kernel in the first pass
-    and kept per parameter version, ntm_amd.model warm_cache) -> persistent GRU kernel over [B,T] -> per-stream ESR sums
-    against a resident target -> all-reduce of 4 fp64 scalars.
+    and kept per parameter version, ntm_amd.model warm_cache) -> persistent GRU kernel over [B,T] with the per-stream ESR
+    sums against a resident target accumulated in its output flush (RNN.forward_esr; --esr pass: a separate streaming
+    pass) -> all-reduce of 4 fp64 scalars.
 The target is the output of the first (untimed) pass, so the ESR of every timed pass must be
 exactly 0.0 -- a full-size determinism check -- and stream 0 carries the input of golden G6 so the
 result is also checked against the REFERENCE's own output on 65 536 samples.
@@ -291,7 +292,7 @@ def other_workloads(a, dev, check):
     return out
 
 
-def live_traffic(kernel_regex=r"gru_mfma2_kernel<true, false, 0, 0, 16, false>"):
+def live_traffic(kernel_regex, extra_args=()):
     """HBM bytes per launch of the headline kernel, measured in this run: two child processes
     `rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 2 ...` (separate passes, kernel trace
     only, the interpreter directly behind `--`: the combination MI355X_MICROARCH.md prescribes), the median over the
@@ -313,7 +314,7 @@ def live_traffic(kernel_regex=r"gru_mfma2_kernel<true, false, 0, 0, 16, false>")
                 d = os.path.join(tmp, c)
                 cmd = [prof, "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
                        os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--other", "off",
-                       "--traffic", "off"]
+                       "--traffic", "off"] + list(extra_args)
                 env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
                 env["TMPDIR"] = "/tmp"
                 r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=120)
@@ -463,6 +464,10 @@ def main():
     ap.add_argument("--other", default="auto", choices=["auto", "on", "off"],
                     help="attach `other_workloads` (configs[2], [3] and the per-GPU shapes of configs[4]) to the line: "
                          "auto = only for the default single-GPU workload (4096 x 65536)")
+    ap.add_argument("--esr", default="fused", choices=["fused", "pass"],
+                    help="the loss leg of a step: fused = the ESR sums are accumulated inside the recurrent launch "
+                         "(RNN.forward_esr / ntm_gru_forward_esr); pass = forward launch, then the streaming ESR pass on a side "
+                         "stream under the next step's launch (rounds 1-2)")
     ap.add_argument("--traffic", default="auto", choices=["auto", "live", "file", "off"],
                     help="roofline.traffic of the headline kernel: live = two rocprofv3 --pmc child passes in this run (auto: when "
                          "rocprofv3 is available), file = the newest profiles/*pmc_traffic_mfma2*.json, off = null")
@@ -529,6 +534,7 @@ def main():
 
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     side = torch.cuda.Stream(device=dev)       # the loss leg (ESR sums + the job-wide reduction) runs here
+    fused_esr = a.esr == "fused" and a.variant == "auto"     # an explicitly chosen kernel variant takes the separate ESR pass
 
     def one_pass(target, evs=(ev0, ev1)):
         """One step: model.predict(x) (code/model.py:218-246, unrolled so the events bracket the main launch) and,
@@ -541,14 +547,21 @@ def main():
         model.warm_start()
         model.hidden = model.hidden.expand(1, B, 64).contiguous()
         evs[0].record()
-        y = model.forward(x)
+        if target is not None and fused_esr:
+            # forward + ESR sums in ONE call (ntm_gru_forward_esr: the sums ride in the recurrent launch's y-tile flush)
+            y, s = model.forward_esr(x, target, skip=INIT_LEN)
+        else:
+            y, s = model.forward(x), None
         evs[1].record()
         pend = None
         if target is not None:
             side.wait_event(evs[1])
             y.record_stream(side)
-            with torch.cuda.stream(side):
-                s = esr_sums(y, target, skip=INIT_LEN)
+            with torch.cuda.stream(side):       # the per-segment scalars (and, with --esr pass, the 2 GB ESR pass itself)
+                if s is None:
+                    s = esr_sums(y, target, skip=INIT_LEN)
+                else:
+                    s.record_stream(side)
                 n = T - INIT_LEN
                 pend = D.local_loss_sums((s[:, 0] / n) / (s[:, 1] / n + ESR_EPS), s)
         return y, pend
@@ -645,7 +658,9 @@ def main():
     if a.variant == "f16x3":
         flop_per_sample, peak_tflops, dtype = 3 * 2 * 12288 + 2 * (192 + 64), 2500.0, "f16x3 products, f32 accumulate"
     tflops = flop_per_sample * B * T / kern_s / 1e12
-    hbm_gbs = BYTES_PER_SAMPLE * B * T / kern_s / 1e9
+    # algorithmic bytes of the dominant launch: x in + y out, + the target it reads when the loss leg rides in it
+    bytes_per_sample = BYTES_PER_SAMPLE + (4 if fused_esr else 0)
+    hbm_gbs = bytes_per_sample * B * T / kern_s / 1e9
     checks = {"esr_vs_first_pass": res["mean_segment_loss"] if res else None, "segments": res["segments"] if res else None,
               "every_timed_step_same_loss": steps_identical}
     if gold is not None:
@@ -661,11 +676,12 @@ def main():
     traffic, traffic_source = None, None
     if (B, T) == (4096, 65536) and a.variant in ("auto", "mfma2") and a.traffic != "off":
         profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+        rx = r"gru_mfma2_kernel<true, false, 0, 0, 16, false, " + ("true>" if fused_esr else "false>")
         if a.traffic == "live" or (a.traffic == "auto" and world == 1 and not profiled):     # never a profiler inside a profiler
-            traffic, traffic_source = live_traffic()
+            traffic, traffic_source = live_traffic(rx, ["--esr", a.esr])
         if traffic is None:
             import glob
-            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic_mfma2*.json")))
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic_mfma2_esr*.json" if fused_esr else "*pmc_traffic_mfma2.json")))
             if files:
                 why = f"; live passes: {traffic_source}" if traffic_source else ""
                 traffic = json.load(open(files[-1]))["hbm_bytes_per_launch_corrected"]
@@ -678,7 +694,9 @@ def main():
         "scaling": a.scaling, "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": f"GRU-HS[64] CHOWTAPE weights, {total_segments} segments x {T} samples fp32 "
                                f"({B} on rank 0), "
-                               f"predict (warm-start state, kept per parameter version after the first pass, + persistent GRU kernel) + ESR sums on a side stream under the next step's launch + one all-reduce of the per-step loss scalars",
+                               f"predict (warm-start state, kept per parameter version after the first pass, + persistent GRU kernel) + ESR sums "
+                               + ("accumulated inside the recurrent launch" if fused_esr else "as a streaming pass on a side stream under the next step's launch")
+                               + " + one all-reduce of the per-step loss scalars",
                    "segments_total": total_segments, "segments_rank0": B, "samples_per_segment": T, "kernel": a.variant,
                    "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
         "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if grouped else "none (single process)",
@@ -687,10 +705,11 @@ def main():
         "roofline": {"bound": "mfma", "achieved": tflops, "peak": peak_tflops, "unit": "TFLOP/s",
                      "frac": tflops / peak_tflops, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": {"auto": "gru_mfma2_kernel", "mfma2": "gru_mfma2_kernel", "mfma": "gru_mfma_kernel",
-                                "valu": "gru_valu_kernel", "f16x3": "gru_mfma2_kernel<f16x3>", "mfma4": "gru_mfma4_kernel"}[a.variant],
+                                "valu": "gru_valu_kernel", "f16x3": "gru_mfma2_kernel<f16x3>", "mfma4": "gru_mfma4_kernel"}[a.variant]
+                               + ("<ESR: forward + loss sums>" if fused_esr else ""),
                      "kernel_ms": 1e3 * kern_s, "flop_per_sample": flop_per_sample,
                      "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": hbm_gbs / PEAK_HBM_GBS, "bytes_per_sample": BYTES_PER_SAMPLE,
+                             "frac": hbm_gbs / PEAK_HBM_GBS, "bytes_per_sample": bytes_per_sample,
                              "copy_kernel_measured": hbm_copy_gbs}},
         "checks": checks,
     }

@@ -32,7 +32,7 @@ extern "C" {
 #define NTM_EHIP (-2)    /* HIP runtime error (launch failed, no device)               */
 #define NTM_EDELAY (-3)  /* reserved for host-side delay-range checks                  */
 
-#define NTM_ABI_VERSION 4 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag.  3: the TCN scratch is padded (ntm_tcn_scratch_floats grew), dilation / length limits.  4: ntm_diffdel_gru_forward is ONE fused launch where the matrix-pipe kernel runs (+ ntm_diffdel_gru_forward_ex) */
+#define NTM_ABI_VERSION 5 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag.  3: the TCN scratch is padded (ntm_tcn_scratch_floats grew), dilation / length limits.  4: ntm_diffdel_gru_forward is ONE fused launch where the matrix-pipe kernel runs (+ ntm_diffdel_gru_forward_ex).  5: ntm_gru_forward_esr */
 
 #define NTM_HIDDEN 64 /* hidden size of every shipped checkpoint (HS[64]): matrix-pipe and low-latency kernels.
                          H = 8, 16, 32 (the reference's constructor default is 8, code/model.py:22; its training
@@ -82,6 +82,23 @@ int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, 
                        const float *w_o, const float *b_o, int H, const float *x, float *y,
                        int64_t B, int64_t T, int64_t x_stride_b, int64_t y_stride_b,
                        float *h_state, int variant, void *stream);
+
+/*
+ * RNN.forward + the ESR sums of the loss loop in ONE call: replaces
+ *     output = model(input)  ...  loss_fcn(output[..., INIT_LEN:], target[..., INIT_LEN:])      (code/test-model.py:346,386-388)
+ * for the ESR entry of the loss dict.  Arguments as ntm_gru_forward (kernel choice = NTM_GRU_AUTO), then
+ * target [B,T] contiguous, skip (= INIT_LEN), and esr_out [B,2] fp64 (device):
+ *     esr_out[2b] = sum_{n >= skip} (target - y)^2,   esr_out[2b+1] = sum_{n >= skip} target^2      of stream b
+ * -- the per-sample terms of ntm_esr_sums (fp32 difference, fp64 products and sums), added in a fixed order.  Where the
+ * matrix-pipe kernel runs (H = 64, B > NTM_GRU_LAT_MAX_B, skip a multiple of 4) the sums are accumulated inside that launch,
+ * in the y-tile flush where the outputs sit in registers (the separate 2 GB pass, overlapped with the next launch, cost
+ * that launch 0.37 ms at 4096 x 65 536); elsewhere it is the forward launch followed by the streaming pass (then y must
+ * be contiguous).  target must not alias y.
+ */
+int ntm_gru_forward_esr(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                        const float *w_o, const float *b_o, int H, const float *x, float *y,
+                        int64_t B, int64_t T, int64_t x_stride_b, int64_t y_stride_b, float *h_state,
+                        const float *target, int64_t skip, double *esr_out, void *stream);
 
 /*
  * Replaces TimeVaryingDelayLine.forward(x, dt, warmup), code/model.py:269-320.

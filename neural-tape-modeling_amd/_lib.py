@@ -24,6 +24,7 @@ _SIGNATURES = {
     "ntm_last_error": (ctypes.c_char_p, []),
     "ntm_gru_forward": (_int, [_vp] * 6 + [_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "ntm_gru_forward_ex": (_int, [_vp] * 6 + [_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp]),
+    "ntm_gru_forward_esr": (_int, [_vp] * 6 + [_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp]),
     "ntm_delay_forward": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _int, _int, _vp, _vp]),
     "ntm_diffdel_gru_forward": (_int, [_vp] * 5 + [_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _int,
                                                    _vp, _vp]),
@@ -60,7 +61,7 @@ LAB_VARIANTS = ("mfma", "valu", "mfma3", "mfma4")
 
 _lib = None
 _lab = None
-ABI_VERSION = 4          # include/ntm.h NTM_ABI_VERSION this binding was written against
+ABI_VERSION = 5          # include/ntm.h NTM_ABI_VERSION this binding was written against
 HIDDEN_SIZES = (8, 16, 32, 64)
 NTM_DIFFDEL_AUTO, NTM_DIFFDEL_TWO_PASS, NTM_DIFFDEL_FUSED = 0, 1, 2
 DIFFDEL_MODES = {"auto": NTM_DIFFDEL_AUTO, "two_pass": NTM_DIFFDEL_TWO_PASS, "fused": NTM_DIFFDEL_FUSED}

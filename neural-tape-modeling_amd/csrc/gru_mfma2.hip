@@ -151,7 +151,14 @@ __device__ __forceinline__ f32x4 pack_hl(const f16x4 hi, const f16x4 lo)
 //   The arithmetic is delay_math.h's, i.e. bit-identical to the separate pass (delay_apply_kernel) on the same pre_d.
 //   The range check (d > D or NaN: the reference's assert, code/model.py:284) raises the caller's sticky flag; the
 //   carried buffer is moved on by delay_update_kernel afterwards (it must see the flag of EVERY workgroup).
-template <bool PRESCALE, bool STAMP, int ABL = 0, int ENGINE = 0, int YPN = 16, bool FUSE = false>
+// ESR = true: the loss leg of the step (code/test-model.py:386-388) in the same launch.  The per-stream sums
+//   sum (t - y)^2 and sum t^2 over samples [esr_skip, T) ride in the y-tile flush: a thread's 4 outputs of the tile are in
+//   registers there anyway; the matching 16 bytes of the target were fetched one tile earlier (loads of a step ahead of its
+//   stores); products and sums in fp64 as esr_sums_kernel forms them (same per-sample terms, other summation order).
+//   As a separate pass on a side stream the 2 GB ESR kernel overlapped the NEXT step's launch and cost that launch
+//   0.37 ms -- its vector instructions take issue slots and datapath from the one wave per SIMD that feeds the matrix
+//   pipe; here it is ~25 instructions per thread and tile.
+template <bool PRESCALE, bool STAMP, int ABL = 0, int ENGINE = 0, int YPN = 16, bool FUSE = false, bool ESR = false>
 __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 {
     using namespace m2;
@@ -271,12 +278,46 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     const bool y_row_ok = (s0 + (tid >> 4)) < a.B;
     float *const y_row = a.y + (y_row_ok ? s0 + (tid >> 4) : s0) * a.ys + 4 * (tid & 15);
     (void)y_row;
-    auto flush_y_tile = [&](int64_t tile, auto whole_c) {
-        constexpr bool WHOLE = decltype(whole_c)::value && NTM2_HKTRIM;
+    auto flush_sum = [&](int64_t tile) -> f32x4 {
         const float *src = yp + (tile & 1) * YPN * YP_Q + (tid >> 4) * YS + 4 * (tid & 15);
         f32x4 v = {bo, bo, bo, bo};
 #pragma unroll
         for (int pl = 0; pl < YPN; ++pl) v += *(const f32x4 *)(src + pl * YP_Q);
+        return v;
+    };
+    // ---- ESR: per-thread fp64 sums over the thread's sample column of its stream; the target tile in flight ----------
+    double esr_e = 0.0, esr_t = 0.0;
+    f32x4 esr_tg = {0.0f, 0.0f, 0.0f, 0.0f};
+    int64_t esr_tile = -1;                                   // which tile esr_tg holds (wave-uniform)
+    const float *const esr_row = ESR ? a.tgt + (y_row_ok ? s0 + (tid >> 4) : s0) * T + 4 * (tid & 15) : nullptr;
+    (void)esr_e; (void)esr_t; (void)esr_tg; (void)esr_tile; (void)esr_row;
+    // ONE unconditional 16-byte load into esr_tg on the common path; the general form (first flush of a launch, ragged
+    // tail) fetches into registers of its own -- a second, conditional load path into the SAME registers makes hipcc drain
+    // the VM counter in front of the common one
+    auto esr_fetch_whole = [&](int64_t tile) {
+        esr_tg = *(const f32x4y *)(esr_row + tile * TT);
+        esr_tile = tile;
+    };
+    auto esr_accumulate = [&](int64_t tile, const f32x4 v, auto whole_c) {
+        constexpr bool WHOLE = decltype(whole_c)::value;
+        const int64_t gt = tile * TT + 4 * (tid & 15);
+        f32x4 tg = esr_tg;
+        if (__builtin_expect(esr_tile != tile, 0)) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) tg[c] = gt + c < T ? esr_row[tile * TT + c] : 0.0f;
+        }
+        if (WHOLE ? gt >= a.esr_skip : true) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (!WHOLE && !(gt + c >= a.esr_skip && gt + c < T)) continue;
+                const float e = tg[c] - v[c];
+                esr_e += (double)e * (double)e;
+                esr_t += (double)tg[c] * (double)tg[c];
+            }
+        }
+    };
+    auto flush_store = [&](int64_t tile, const f32x4 v, auto whole_c) {
+        constexpr bool WHOLE = decltype(whole_c)::value && NTM2_HKTRIM;
         if constexpr (WHOLE) {
             // a tile that lies entirely inside [0, T): one predicated 16-byte store (any alignment), nothing else
             if (y_row_ok) {
@@ -307,6 +348,11 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
                 }
             }
         }
+    };
+    auto flush_y_tile = [&](int64_t tile, auto whole_c) {      // sum + (ESR) + store in one go: epilogue, non-ESR steps
+        const f32x4 v = flush_sum(tile);
+        if constexpr (ESR) esr_accumulate(tile, v, std::false_type{});
+        flush_store(tile, v, whole_c);
     };
 
     // ---- FUSE: the delay line, one tile behind the recurrence (see the comment above the kernel) ----------------
@@ -560,17 +606,37 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
                     if (__builtin_expect(dl_stage == 2, 1)) dl_compute(std::bool_constant<(HK > 0)>{});
                 }
                 // the x loads go out before the flush's stores (no VMEM drain between them)
+                f32x4 fv = {0.0f, 0.0f, 0.0f, 0.0f};
+                if constexpr (ESR) {
+                    // the flushed tile's sums and its ESR terms first: they consume the target fetched one tile ago, and
+                    // nothing newer may be in flight when hipcc waits for it (it waits for everything)
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                    if (__builtin_expect(t > 65, 1)) {
+                        fv = flush_sum(next_flush);
+                        esr_accumulate(next_flush, fv, std::bool_constant<(HK > 0)>{});
+                    }
+                }
 #if NTM2_HKTRIM
                 if (__builtin_expect((tile + 2) * TT <= T, 1)) load_x_tile_whole(tile + 1, xr);
                 else if ((tile + 1) * TT < T) load_x_tile(tile + 1, xr);
 #else
                 if (__builtin_expect((tile + 1) * TT < T, 1)) load_x_tile(tile + 1, xr);
 #endif
+                if constexpr (ESR) {
+                    // the next flush's target (tile next_flush + 1 = this tile when t > 65): whole inside the unrolled loop
+                    if (__builtin_expect(t > 65, 1)) {
+                        if (HK > 0) esr_fetch_whole(next_flush + 1);
+                        flush_store(next_flush, fv, std::bool_constant<(HK > 0)>{});
+                        ++next_flush;
+                    }
+                }
                 if constexpr (FUSE) {
                     if (__builtin_expect(dl_on && t > 65, 1)) dl_load_d((int)next_flush, std::bool_constant<(HK > 0)>{});
                     dl_store();
                 }
-                if (__builtin_expect(t > 65, 1)) { flush_y_tile(next_flush, std::bool_constant<(HK > 0)>{}); ++next_flush; }
+                if constexpr (!ESR) {
+                    if (__builtin_expect(t > 65, 1)) { flush_y_tile(next_flush, std::bool_constant<(HK > 0)>{}); ++next_flush; }
+                }
             } else if (HK == 2 || (HK < 0 && ph == 34)) {
                 if (__builtin_expect((tile + 1) * TT < T, 1)) store_x_tile(tile + 1, xr);
                 // FUSE: this thread's pre_d stores of phase 2 have completed; step 35's barrier makes that true of the
@@ -693,6 +759,18 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     // ---- epilogue: remaining y tiles, final state ---------------------------------------------------
     __syncthreads();
     while (next_flush * TT < T) { flush_y_tile(next_flush, std::false_type{}); ++next_flush; }
+    if constexpr (ESR) {
+        // the 16 threads of a stream (one lane group of 16) add their columns in a fixed butterfly order
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+            esr_e += __shfl_xor(esr_e, off, 16);
+            esr_t += __shfl_xor(esr_t, off, 16);
+        }
+        if (y_row_ok && (tid & 15) == 0) {
+            a.esr_out[(s0 + (tid >> 4)) * 2 + 0] = esr_e;
+            a.esr_out[(s0 + (tid >> 4)) * 2 + 1] = esr_t;
+        }
+    }
     if constexpr (FUSE) {
         if (dl_on) {
             // every pre_d tile is stored: make the stores visible to the workgroup, then run the delay tiles that are left
@@ -760,6 +838,11 @@ hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream)
 #else
     if (a.abl || a.dbg) return hipErrorInvalidValue;      // diagnostics live in libntm_lab.so
 #endif
+    if (a.tgt) {        // predict + ESR sums in one launch (exact fp32 engine)
+        if (!a.esr_out || a.engine || (a.esr_skip & 3) || a.esr_skip < 0) return hipErrorInvalidValue;
+        return many ? NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 4, false, true>), smem4)
+                    : NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 16, false, true>), smem16);
+    }
     if (a.engine == 1)
         return many ? NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 1, 4>), smem4)
                     : NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 1, 16>), smem16);

@@ -108,6 +108,43 @@ int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, 
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_gru_forward");
 }
 
+int ntm_gru_forward_esr(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *w_o,
+                        const float *b_o, int H, const float *x, float *y, int64_t B, int64_t T, int64_t x_stride_b,
+                        int64_t y_stride_b, float *h_state, const float *target, int64_t skip, double *esr_out, void *stream)
+{
+    if (B < 0 || T < 0 || skip < 0 || skip > T) return fail(NTM_EINVAL, "ntm_gru_forward_esr: bad size");
+    if (B == 0) return NTM_OK;
+    if (!target || !esr_out) return fail(NTM_EINVAL, "ntm_gru_forward_esr: null pointer");
+    if (target == y) return fail(NTM_EINVAL, "ntm_gru_forward_esr: target must not alias y");
+    // streams the matrix-pipe kernel takes (as ntm_gru_forward's NTM_GRU_AUTO decides): there the sums ride in the launch
+    int64_t fused = 0;
+    if (H == NTM_HIDDEN && B > NTM_GRU_LAT_MAX_B && T > 0 && (skip & 3) == 0) {
+        const int64_t round = 16 * (int64_t)ntm::device_cus();
+        const int64_t full = (B / round) * round, rem = B - full;
+        fused = (full > 0 && rem > 0 && rem <= NTM_GRU_LAT_MAX_B) ? full : B;
+    }
+    if (fused > 0) {
+        if (!w_ih || !w_hh || !b_ih || !b_hh || !w_o || !x || !y) return fail(NTM_EINVAL, "ntm_gru_forward_esr: null pointer");
+        if (x_stride_b < T || y_stride_b < T) return fail(NTM_EINVAL, "ntm_gru_forward_esr: stride < T");
+        ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, fused, T, x_stride_b, y_stride_b, nullptr, 0, 0};
+        a.tgt = target;
+        a.esr_out = esr_out;
+        a.esr_skip = skip;
+        hipError_t e = ntm::launch_gru_mfma2(a, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "ntm_gru_forward_esr");
+    }
+    if (fused < B) {            // the rest: the forward launch the library would pick, then the streaming ESR pass (one row per stream)
+        const int64_t r = B - fused;
+        int rc = ntm_gru_forward(w_ih, w_hh, b_ih, b_hh, w_o, b_o, H, x + fused * x_stride_b, y + fused * y_stride_b, r, T,
+                                 x_stride_b, y_stride_b, h_state ? h_state + fused * H : nullptr, stream);
+        if (rc != NTM_OK) return rc;
+        if (y_stride_b != T) return fail(NTM_EINVAL, "ntm_gru_forward_esr: the streaming ESR pass needs contiguous y rows (stride T)");
+        hipError_t e = ntm::launch_esr(y + fused * T, target + fused * T, r, T, skip, 1, esr_out + 2 * fused, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "ntm_gru_forward_esr");
+    }
+    return NTM_OK;
+}
+
 int ntm_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *w_o,
                     const float *b_o, int H, const float *x, float *y, int64_t B, int64_t T, int64_t x_stride_b,
                     int64_t y_stride_b, float *h_state, void *stream)

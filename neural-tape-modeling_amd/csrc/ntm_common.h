@@ -41,6 +41,10 @@ struct GruArgs {
     int32_t *dl_flag = nullptr;     // sticky range-violation flag (may be null)
     int D = 0;
     int warmup = 0;
+    // predict + loss leg in one launch (gru_mfma2_kernel<ESR>): per-stream sums of (tgt - y)^2 and tgt^2 over [esr_skip, T)
+    const float *tgt = nullptr;     // target [B,T], contiguous
+    double *esr_out = nullptr;      // [B,2] fp64
+    int64_t esr_skip = 0;           // multiple of 4
 };
 
 }  // namespace ntm

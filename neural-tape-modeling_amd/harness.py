@@ -40,9 +40,9 @@ def compute_loss(model, input, target, d_traj=None, INIT_LEN=1024):
     Returns the job-wide dict of distributed.reduce_loss_sums plus this rank's output tensor."""
     if isinstance(model, DiffDelRNN):
         output, _ = model.predict(input, d_traj)
+        s = esr_sums(output, target, skip=INIT_LEN)               # cut first INIT_LEN samples (:367-369)
     else:
-        output = model.predict(input)
-    s = esr_sums(output, target, skip=INIT_LEN)                   # cut first INIT_LEN samples (:367-369)
+        output, s = model.predict_esr(input, target, skip=INIT_LEN)     # the ESR sums ride in the recurrent launch
     n = input.shape[-1] - INIT_LEN
     per_seg = (s[:, 0] / n) / (s[:, 1] / n + ESR_EPS)
     res = distributed.reduce_loss_sums(per_seg, s)

@@ -129,6 +129,22 @@ class _GRUHead(torch.nn.Module):
         self.hidden = h
         return y
 
+    def _gru_esr(self, xbt, tbt, skip):
+        """xbt, tbt [B,T] fp32 on HIP -> (y [B,T], per-stream ESR sums (B,2) fp64 over samples [skip,T)) through ONE C-ABI
+        call (ntm_gru_forward_esr): where the matrix-pipe kernel runs the sums ride in the recurrent launch."""
+        B, T = xbt.shape
+        _require_hip(self.GRU.weight_hh_l0, "model parameters (call .to('cuda'))")
+        h = self._hidden_for(B, xbt.device)
+        y = torch.empty_like(xbt)
+        sums = torch.empty(B, 2, device=xbt.device, dtype=torch.float64)
+        g, o = self.GRU, self.output
+        rc = _lib.lib().ntm_gru_forward_esr(ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0),
+                                            ptr(o.weight), ptr(o.bias), self.hidden_size, ptr(xbt), ptr(y), B, T, T, T, ptr(h),
+                                            ptr(tbt), int(skip), ptr(sums), _lib.current_stream())
+        _lib.check(rc, "ntm_gru_forward_esr")
+        self.hidden = h
+        return y, sums
+
     @torch.no_grad()
     def forward_into(self, x2d, y2d):
         """Stateful forward on ROW-STRIDED [B,Tc] fp32 views (unit stride along time), e.g. the time chunk
@@ -193,6 +209,32 @@ class RNN(_GRUHead):
         if self.skip:
             y += xbt
         return y.view(xbt.shape[0], 1, xbt.shape[1])
+
+    @torch.no_grad()
+    def forward_esr(self, x, target, skip=0):
+        """forward(x) AND the per-stream ESR sums against `target` over samples [skip, T) -- `output = model(input)` followed
+        by the ESR entry of the loss loop (code/test-model.py:346, :386-388) -- in one call: (y (N,1,T), sums (N,2) fp64 =
+        [sum (t-y)^2, sum t^2]), the same numbers as `esr_sums(self(x), target, skip)` up to fp64 summation order.  With
+        `kernel_variant == "auto"` and no skip connection it is ONE launch where the matrix-pipe kernel runs."""
+        xbt = _as_bt(x, "RNN.forward_esr")
+        tbt = _as_bt(target, "RNN.forward_esr")
+        if tbt.shape != xbt.shape:
+            raise RuntimeError(f"shape mismatch: x {tuple(x.shape)} vs target {tuple(target.shape)}")
+        if self.kernel_variant != "auto" or self.skip:
+            y = self.forward(x)
+            return y, esr_sums(y, target, skip)
+        y, sums = self._gru_esr(xbt, tbt, skip)
+        return y.view(xbt.shape[0], 1, xbt.shape[1]), sums
+
+    @torch.no_grad()
+    def predict_esr(self, input, target, skip=0):
+        """predict(input) + the ESR sums against `target` over [skip, T): initialize_hidden, warm_start, forward_esr."""
+        B = input.shape[0]
+        self.initialize_hidden()
+        self.warm_start()
+        if B != 1:
+            self.hidden = self.hidden.expand(1, B, self.hidden_size).contiguous()
+        return self.forward_esr(input, target, skip)
 
     @torch.no_grad()
     def predict(self, input, segment_length=None):

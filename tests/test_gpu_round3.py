@@ -577,3 +577,79 @@ def test_fused_diffdel_step_many_groups_build(ntm, B, T, D):
     rows = [0, 15, 16, 4095, 4096, 4111, B - 1]
     yo, po, ho, bo = oracle.diffdel_forward(oracle_weights(W_D), x[rows, 0].cpu().numpy(), d_np[rows], h0[rows], b0[rows], threads=4)
     assert np.abs(res["auto"][1][rows, 0].cpu().numpy() - po).max() < TOL and np.abs(res["auto"][0][rows, 0].cpu().numpy() - yo).max() < TOL
+
+
+# ----------------------------------------------------------------------------- forward + ESR sums in one launch
+@pytest.mark.parametrize("B,T,skip", [(1040, 64, 0), (1040, 100, 4), (2050, 4096, 1024), (4096 + 40, 1500, 1024), (1100, 333, 332),
+                                     (5000, 700, 5), (16, 900, 64), (1, 70, 0), (1040, 130, 128)])
+def test_forward_esr_equals_forward_plus_esr_pass(ntm, B, T, skip):
+    """RNN.forward_esr / ntm_gru_forward_esr (the loss leg accumulated in the recurrent launch's output flush) against
+    forward() followed by the streaming ESR pass: y and the carried state bit for bit, the per-stream sums to fp64
+    summation order, and against the oracle.  Ragged batches and lengths, skip at / beyond tile borders, a skip that is
+    not a multiple of 4 and small batches (both: forward launch + streaming pass inside the entry point), a remainder
+    behind a whole device round (fused kernel + low-latency kernel)."""
+    rng = np.random.default_rng(B + 7 * T + skip)
+    x = rng.uniform(-0.5, 0.5, (B, 1, T)).astype(np.float32)
+    t = (0.3 * np.tanh(2 * x) + 0.02 * rng.standard_normal(x.shape)).astype(np.float32)
+    h0 = rng.uniform(-0.3, 0.3, (1, B, 64)).astype(np.float32)
+    m = ntm.harness.build_model(W_G)
+    m.hidden = dev(h0)
+    y1, s1 = m.forward_esr(dev(x), dev(t), skip)
+    h1 = m.hidden.clone()
+    m.hidden = dev(h0)
+    y2 = m.forward(dev(x))
+    s2 = ntm.model.esr_sums(y2, dev(t), skip)
+    assert torch.equal(y1, y2) and torch.equal(h1, m.hidden)
+    assert s1.shape == (B, 2) and s1.dtype == torch.float64
+    a, b = s1.cpu().numpy(), s2.cpu().numpy()
+    assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max())
+    rows = sorted({0, B // 2, B - 1})
+    so = oracle.esr_sums(y1[rows, 0].cpu().numpy(), t[rows, 0], skip)
+    assert np.abs(a[rows] - so).max() <= 1e-9 * max(1.0, np.abs(so).max())
+    if skip == T:
+        assert not a.any()
+
+
+def test_forward_esr_raw_entry_point_and_predict_esr(ntm):
+    """ntm_gru_forward_esr through raw ctypes: a strided x view, refusals (target aliasing y, negative skip, null
+    pointers), and predict_esr = predict + esr_sums on golden g1's programme material; a model with an explicitly chosen
+    kernel variant or a skip connection takes the two calls and gives the same numbers."""
+    L = ntm._lib.lib()
+    g = load("g1_predict_16x8192.npz")
+    x = dev(np.repeat(g["x"].reshape(16, 1, -1), 70, axis=0))            # 1120 streams: the matrix-pipe kernel
+    tgt = dev(np.repeat(g["y"].reshape(16, 1, -1), 70, axis=0))
+    m = ntm.harness.build_model(W_G)
+    y, s = m.predict_esr(x, tgt, skip=1024)
+    y_ref = m.predict(x)
+    assert torch.equal(y, y_ref)
+    s_ref = ntm.model.esr_sums(y_ref, tgt, 1024)
+    assert np.abs(s.cpu().numpy() - s_ref.cpu().numpy()).max() <= 1e-12 * float(s_ref.max())
+    n = x.shape[-1] - 1024
+    esr = ((s[:, 0] / n) / (s[:, 1] / n + ntm.model.ESR_EPS)).cpu().numpy()
+    assert esr.max() < 1e-9                                              # the target IS the reference's own output
+    for variant, skipc in (("mfma2", False), ("auto", True)):
+        m2 = ntm.harness.build_model(W_G)
+        m2.kernel_variant, m2.skip = variant, skipc
+        y2, s2 = m2.predict_esr(x, tgt, skip=1024)
+        y2r = m2.predict(x)
+        assert torch.equal(y2, y2r)
+        assert np.abs(s2.cpu().numpy() - ntm.model.esr_sums(y2r, tgt, 1024).cpu().numpy()).max() <= 1e-12 * float(s2.max())
+    # raw entry: row-strided x
+    w = {k: v.cuda() for k, v in ntm.weights.load_state_dict(W_G).items()}
+    B, T = 1040, 256
+    big = torch.rand(B, 300, device="cuda") - 0.5
+    xv = big[:, 20:20 + T]
+    t2 = torch.rand(B, T, device="cuda") - 0.5
+    yv, out = torch.empty(B, T, device="cuda"), torch.empty(B, 2, device="cuda", dtype=torch.float64)
+    h = torch.zeros(B, 64, device="cuda")
+    args = lambda tg, sk, o: [p(w["GRU.weight_ih_l0"]), p(w["GRU.weight_hh_l0"]), p(w["GRU.bias_ih_l0"]), p(w["GRU.bias_hh_l0"]),   # noqa: E731
+                              p(w["output.weight"]), p(w["output.bias"]), 64, p(xv), p(yv), B, T, 300, T, p(h), tg, sk, o, None]
+    assert L.ntm_gru_forward_esr(*args(p(t2), 0, p(out))) == 0
+    mm = ntm.harness.build_model(W_G)
+    mm.initialize_hidden()
+    yr = mm(xv.contiguous().unsqueeze(1))
+    assert torch.equal(yv, yr[:, 0]) and torch.equal(h.unsqueeze(0), mm.hidden)
+    assert np.abs(out.cpu().numpy() - ntm.model.esr_sums(yr, t2.unsqueeze(1), 0).cpu().numpy()).max() < 1e-10
+    assert L.ntm_gru_forward_esr(*args(p(yv), 0, p(out))) == -1 and b"alias" in L.ntm_last_error()
+    assert L.ntm_gru_forward_esr(*args(p(t2), -4, p(out))) == -1
+    assert L.ntm_gru_forward_esr(*args(None, 0, p(out))) == -1 and L.ntm_gru_forward_esr(*args(p(t2), 0, None)) == -1

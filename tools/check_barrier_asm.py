@@ -34,7 +34,7 @@ def check(defines=()):
     kernels = re.findall(r"^(_ZN3ntm16gru_mfma2_kernel\w+):[^\n]*\n(.*?)\n\s*\.amdhsa_kernel", text, flags=re.S | re.M)
     checked = 0
     for name, body in kernels:
-        m = re.match(r"_ZN3ntm16gru_mfma2_kernelILb1ELb(\d)ELi(\d+)ELi(\d)ELi(\d+)E(?:Lb\dE)?EE", name)
+        m = re.match(r"_ZN3ntm16gru_mfma2_kernelILb1ELb(\d)ELi(\d+)ELi(\d)ELi(\d+)E(?:Lb\dE)*EE", name)
         if not m or m.group(1) == "1" or m.group(2) != "0":
             continue                                      # STAMP / ablation builds are diagnostics (they use lgkmcnt(0))
         # Instructions in layout order, labels and branches kept as block boundaries.  The step is inlined several times
