@@ -294,7 +294,7 @@ def other_workloads(a, dev, check):
 
 def live_traffic(kernel_regex, extra_args=()):
     """HBM bytes per launch of the headline kernel, measured in this run: two child processes
-    `rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 2 ...` (separate passes, kernel trace
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 5 ...` (separate passes, kernel trace
     only, the interpreter directly behind `--`: the combination MI355X_MICROARCH.md prescribes), the median over the
     full-size launches, FETCH_SIZE doubled (gfx950 reports half of a wide coalesced streaming read), KB of 1024 bytes.
     -> (bytes, source note) or (None, reason)."""
@@ -313,7 +313,7 @@ def live_traffic(kernel_regex, extra_args=()):
             for c in ("FETCH_SIZE", "WRITE_SIZE"):
                 d = os.path.join(tmp, c)
                 cmd = [prof, "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
-                       os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--other", "off",
+                       os.path.abspath(__file__), "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--other", "off",
                        "--traffic", "off"] + list(extra_args)
                 env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
                 env["TMPDIR"] = "/tmp"
@@ -330,7 +330,7 @@ def live_traffic(kernel_regex, extra_args=()):
     except Exception as e:                                   # a profiler hiccup must never cost the bench line
         return None, f"{type(e).__name__}: {e}"[:200]
     return (2.0 * med["FETCH_SIZE"] + med["WRITE_SIZE"]) * 1024.0, (
-        f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes of this command at 2 steps "
+        f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes of this command at 5 steps "
         f"(median of the full-size launches: FETCH {med['FETCH_SIZE']:.0f} KB x 2 (gfx950 correction) + WRITE {med['WRITE_SIZE']:.0f} KB)")
 
 
