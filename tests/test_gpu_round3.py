@@ -581,6 +581,7 @@ def test_fused_diffdel_step_many_groups_build(ntm, B, T, D):
 
 # ----------------------------------------------------------------------------- forward + ESR sums in one launch
 @pytest.mark.parametrize("B,T,skip", [(1040, 64, 0), (1040, 100, 4), (2050, 4096, 1024), (4096 + 40, 1500, 1024), (1100, 333, 332),
+                                     (5136, 1500, 1024), (8192, 700, 64),        # more groups than CUs: the small-LDS build
                                      (5000, 700, 5), (16, 900, 64), (1, 70, 0), (1040, 130, 128)])
 def test_forward_esr_equals_forward_plus_esr_pass(ntm, B, T, skip):
     """RNN.forward_esr / ntm_gru_forward_esr (the loss leg accumulated in the recurrent launch's output flush) against
