@@ -33,9 +33,10 @@ int ntm_lab_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih,
 
 /*
  * DIAGNOSTIC ONLY (never timed): an MFMA kernel (variant NTM_GRU_MFMA or NTM_GRU_MFMA2) with
- * s_memtime stamps.  stamps[(B+15)/16][4][6] (device, uint64) receives per-wave cycle sums of six
- * step segments over the whole launch (segment names: tools/stamp_profile.py).  Outputs are the
- * same as ntm_gru_forward.
+ * s_memtime stamps.  stamps[(B+15)/16][4][12] (device, uint64) receives per-wave cycle sums of six
+ * step segments over the whole launch in slots 0-5 (segment names: tools/stamp_profile.py) and, for NTM_GRU_MFMA2, the same
+ * six segments over the phase-2 (housekeeping) steps alone in slots 6-11.  Outputs are the same as ntm_gru_forward.
+ * With NTM_LAB_STAMP_ESR set in the environment the stamped build of the forward + ESR-sums variant runs (x as target).
  */
 int ntm_debug_gru_stamps(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
                          const float *w_o, const float *b_o, const float *x, float *y, int64_t B,

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma_kernel(GruArgs a)
     }
     if constexpr (STAMP) {
         if (a.dbg && l == 0)
-            for (int k = 0; k < 6; ++k) a.dbg[((size_t)blockIdx.x * 4 + w) * 6 + k] = seg[k];
+            for (int k = 0; k < 6; ++k) a.dbg[((size_t)blockIdx.x * 4 + w) * 12 + k] = seg[k];   // 12 slots per wave: the MFMA2 stamps use all of them
     }
 
     __syncthreads();

@@ -162,7 +162,7 @@ template <bool PRESCALE, bool STAMP, int ABL = 0, int ENGINE = 0, int YPN = 16, 
 __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 {
     using namespace m2;
-    unsigned long long seg[6] = {0, 0, 0, 0, 0, 0}, last_ = 0, ts_[6];
+    unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0, ts_[6];    // [6..11]: the phase-2 steps alone
     (void)seg; (void)last_; (void)ts_;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *hb = smem;                  // [2][4 k][16 stream][20]
@@ -280,6 +280,8 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     (void)y_row;
     auto flush_sum = [&](int64_t tile) -> f32x4 {
         const float *src = yp + (tile & 1) * YPN * YP_Q + (tid >> 4) * YS + 4 * (tid & 15);
+        // (hipcc keeps four of the reads in flight; issuing all sixteen ahead of the first add was measured: +38 VGPRs and
+        //  the plain launch 0.35 ms SLOWER, 55.35 against 55.00 ms on one box -- the regular steps' code changed with it)
         f32x4 v = {bo, bo, bo, bo};
 #pragma unroll
         for (int pl = 0; pl < YPN; ++pl) v += *(const f32x4 *)(src + pl * YP_Q);
@@ -722,6 +724,11 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
             seg[0] += ts_[0] - last_;
 #pragma unroll
             for (int k = 1; k < 6; ++k) seg[k] += ts_[k] - ts_[k - 1];
+            if (HK == 1 || (HK < 0 && ph == 2)) {      // the heavy housekeeping step by itself
+                seg[6] += ts_[0] - last_;
+#pragma unroll
+                for (int k = 1; k < 6; ++k) seg[6 + k] += ts_[k] - ts_[k - 1];
+            }
             last_ = ts_[5];
         }
     };
@@ -753,7 +760,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     }
     if constexpr (STAMP) {
         if (a.dbg && l == 0)
-            for (int k = 0; k < 6; ++k) a.dbg[((size_t)blockIdx.x * 4 + w) * 6 + k] = seg[k];
+            for (int k = 0; k < 12; ++k) a.dbg[((size_t)blockIdx.x * 4 + w) * 12 + k] = seg[k];
     }
 
     // ---- epilogue: remaining y tiles, final state ---------------------------------------------------
@@ -834,6 +841,7 @@ hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream)
         NTM2_ABL_CASE(3) NTM2_ABL_CASE(7) NTM2_ABL_CASE(18) NTM2_ABL_CASE(39) NTM2_ABL_CASE(55) NTM2_ABL_CASE(63)
         default: break;
     }
+    if (a.dbg && a.tgt) return NTM2_LAUNCH((gru_mfma2_kernel<true, true, 0, 0, 16, false, true>), smem16);
     if (a.dbg) return NTM2_LAUNCH((gru_mfma2_kernel<true, true>), smem16);
 #else
     if (a.abl || a.dbg) return hipErrorInvalidValue;      // diagnostics live in libntm_lab.so

@@ -5,6 +5,7 @@
 #include "ntm_lab.h"
 #include "ntm_common.h"
 
+#include <cstdlib>
 #include <string>
 
 namespace {
@@ -50,6 +51,18 @@ int ntm_debug_gru_stamps(const float *w_ih, const float *w_hh, const float *b_ih
 {
     if (!stamps || !x || !y || B <= 0 || T <= 0) return fail(NTM_EINVAL, "ntm_debug_gru_stamps: bad argument");
     ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, T, T, (unsigned long long *)stamps, 0, 0};
+    if (getenv("NTM_LAB_STAMP_ESR")) {          // diagnostic: the stamped build of the forward + ESR-sums variant (x as target)
+        static double *scratch = nullptr;
+        static int64_t cap = 0;
+        if (cap < B) {
+            if (scratch) (void)hipFree(scratch);
+            if (hipMalloc(&scratch, (size_t)B * 2 * sizeof(double)) != hipSuccess) return fail(NTM_EHIP, "ntm_debug_gru_stamps: hipMalloc");
+            cap = B;
+        }
+        a.tgt = x;
+        a.esr_out = scratch;
+        a.esr_skip = 0;
+    }
     hipError_t e = variant == NTM_GRU_MFMA ? ntm::launch_gru_mfma(a, (hipStream_t)stream)
                                            : ntm::launch_gru_mfma2(a, (hipStream_t)stream);
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_debug_gru_stamps");

@@ -477,13 +477,13 @@ def test_diagnostic_entry_points_run(ntm):
     yo, _ = oracle.gru_forward(oracle_weights(W_G), xh)
     for variant in (1, 3):
         y = torch.empty_like(x); h = torch.zeros(B, 64, device="cuda")
-        st = torch.zeros(2, 4, 6, dtype=torch.int64, device="cuda")
+        st = torch.zeros(2, 4, 12, dtype=torch.int64, device="cuda")      # [..., :6] every step, [..., 6:] the phase-2 steps alone (MFMA2)
         rc = L.ntm_debug_gru_stamps(P(g.weight_ih_l0), P(g.weight_hh_l0), P(g.bias_ih_l0), P(g.bias_hh_l0), P(o.weight),
                                     P(o.bias), P(x), P(y), B, T, P(h), P(st), variant, None)
         assert rc == 0, L.ntm_last_error()
         torch.cuda.synchronize()
         assert np.abs(y.cpu().numpy() - yo).max() < TOL
-        assert (st.cpu().numpy() > 0).all()
+        assert (st.cpu().numpy()[:, :, :6] > 0).all() and (variant == 1 or (st.cpu().numpy()[:, :, 6:] > 0).all())
     y = torch.empty_like(x); h = torch.zeros(B, 64, device="cuda")
     assert L.ntm_debug_gru_ablate(P(g.weight_ih_l0), P(g.weight_hh_l0), P(g.bias_ih_l0), P(g.bias_hh_l0), P(o.weight),
                                   P(o.bias), P(x), P(y), B, T, P(h), 4, None) == 0

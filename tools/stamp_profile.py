@@ -10,7 +10,7 @@ B, T = 4096, 4096
 m = ntm_amd.harness.build_model(ntm_amd.weights.W_GRU)
 x = torch.rand(B, T, device="cuda") - 0.5
 y = torch.empty_like(x); h = torch.zeros(B, 64, device="cuda")
-st = torch.zeros((B + 15) // 16, 4, 6, dtype=torch.int64, device="cuda")
+st = torch.zeros((B + 15) // 16, 4, 12, dtype=torch.int64, device="cuda")   # [..., 6:12]: the phase-2 (housekeeping) steps alone
 g, o = m.GRU, m.output
 L = ntm_amd._lib.lib()
 LAB = ntm_amd._lib.lab()          # stamps / ablations: diagnostic builds in libntm_lab.so
@@ -22,8 +22,13 @@ for variant in (3, 1):
                                     ptr(o.weight), ptr(o.bias), ptr(x), ptr(y), B, T, ptr(h), ptr(st), variant, None)
         assert rc == 0, L.ntm_last_error()
         torch.cuda.synchronize()
-    s = st.cpu().numpy().astype(np.float64) / T
-    print(f"variant {variant}: s_memtime cycles per step, mean over workgroups (stamped build; shares, not totals)")
+    s = st.cpu().numpy().astype(np.float64)[:, :, :6] / T
+    print(f"variant {variant}{' (forward + ESR sums)' if os.environ.get('NTM_LAB_STAMP_ESR') else ''}: s_memtime cycles per step, mean over workgroups (stamped build; shares, not totals)")
     for w in range(4):
         print(f"  wave {w}: " + "  ".join(f"{n}={s[:, w, k].mean():7.1f}" for k, n in enumerate(NAMES[variant]))
               + f"  total={s[:, w, :].sum(1).mean():7.1f}")
+    if variant == 3:
+        h = st.cpu().numpy().astype(np.float64)[:, :, 6:] / (T // 64)
+        print("  the phase-2 step of a tile alone (x-tile fetch, y-tile flush), cycles per occurrence:")
+        for w in range(4):
+            print(f"  wave {w}: " + "  ".join(f"{n}={h[:, w, k].mean():7.1f}" for k, n in enumerate(NAMES[3])) + f"  total={h[:, w, :].sum(1).mean():7.1f}")
