@@ -32,7 +32,7 @@ extern "C" {
 #define NTM_EHIP (-2)    /* HIP runtime error (launch failed, no device)               */
 #define NTM_EDELAY (-3)  /* reserved for host-side delay-range checks                  */
 
-#define NTM_ABI_VERSION 5 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag.  3: the TCN scratch is padded (ntm_tcn_scratch_floats grew), dilation / length limits.  4: ntm_diffdel_gru_forward is ONE fused launch where the matrix-pipe kernel runs (+ ntm_diffdel_gru_forward_ex).  5: ntm_gru_forward_esr */
+#define NTM_ABI_VERSION 5 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag.  3: the TCN scratch is padded (ntm_tcn_scratch_floats grew), dilation / length limits.  4: ntm_diffdel_gru_forward is ONE fused launch where the matrix-pipe kernel runs (+ ntm_diffdel_gru_forward_ex).  5: ntm_gru_forward_esr, ntm_diffdel_gru_forward_esr */
 
 #define NTM_HIDDEN 64 /* hidden size of every shipped checkpoint (HS[64]): matrix-pipe and low-latency kernels.
                          H = 8, 16, 32 (the reference's constructor default is 8, code/model.py:22; its training
@@ -142,6 +142,19 @@ int ntm_diffdel_gru_forward_ex(const float *w_ih, const float *w_hh, const float
                                const float *d, float *y, float *pre_d, int64_t B, int64_t T,
                                float *h_state, float *dl_state, int D, int warmup, int32_t *err_flag,
                                int mode, void *stream);
+/*
+ * DiffDelRNN.forward + the ESR sums of the loss loop (code/test-model.py:353,386-388) in one call: as
+ * ntm_diffdel_gru_forward (warmup = 0, mode NTM_DIFFDEL_AUTO), then target [B,T] contiguous, skip (= INIT_LEN) and
+ * esr_out [B,2] fp64 = sum (target - y)^2 | sum target^2 over samples [skip, T) of each stream, y being the DELAYED output.
+ * Inside the fused launch (in its delay stage, where a thread's 4 outputs are in registers) when that launch runs and skip is a
+ * multiple of 4; by the streaming ESR pass otherwise.  After a delay-range violation (err_flag raised) the sums are unspecified,
+ * like y.
+ */
+int ntm_diffdel_gru_forward_esr(const float *w_ih, const float *w_hh, const float *b_ih,
+                                const float *b_hh, const float *w_o, int H, const float *x,
+                                const float *d, float *y, float *pre_d, int64_t B, int64_t T,
+                                float *h_state, float *dl_state, int D, int32_t *err_flag,
+                                const float *target, int64_t skip, double *esr_out, void *stream);
 
 /*
  * Per-stream sums for the ESR loss that follows the path in code/test-model.py:250-254,386-388

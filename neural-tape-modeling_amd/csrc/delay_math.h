@@ -79,8 +79,8 @@ __device__ __forceinline__ void delay_general4(const float *xb, const float *db,
         const float dc = full ? dn[c] : db[n0 + c];
         bad |= !(dc <= Dmax);                      // NaN too
         const float v = delay_sample(xb, bb, D, n0 + c, dc);
-        if (full) out[c] = v;
-        else yb[n0 + c] = v;
+        out[c] = v;                                  // (the caller may still want the value: loss sums on y)
+        if (!full) yb[n0 + c] = v;
     }
 }
 

@@ -278,6 +278,8 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     const bool y_row_ok = (s0 + (tid >> 4)) < a.B;
     float *const y_row = a.y + (y_row_ok ? s0 + (tid >> 4) : s0) * a.ys + 4 * (tid & 15);
     (void)y_row;
+    constexpr bool ESR_FLUSH = ESR && !FUSE;     // the sums are taken on y: in the flush for the GRU,
+    constexpr bool ESR_DL = ESR && FUSE;         // in the fused delay stage (on the DELAYED output) for the DiffDelGRU
     auto flush_sum = [&](int64_t tile) -> f32x4 {
         const float *src = yp + (tile & 1) * YPN * YP_Q + (tid >> 4) * YS + 4 * (tid & 15);
         // (hipcc keeps four of the reads in flight; issuing all sixteen ahead of the first add was measured: +38 VGPRs and
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     };
     auto flush_y_tile = [&](int64_t tile, auto whole_c) {      // sum + (ESR) + store in one go: epilogue, non-ESR steps
         const f32x4 v = flush_sum(tile);
-        if constexpr (ESR) esr_accumulate(tile, v, std::false_type{});
+        if constexpr (ESR_FLUSH) esr_accumulate(tile, v, std::false_type{});
         flush_store(tile, v, whole_c);
     };
 
@@ -605,11 +607,15 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
                     // keeps "a load into these registers may be pending" alive around the loop and drains the VM counter
                     // in front of the NEXT loads -- the x tile fetched just before them, a full memory round trip.
                     __builtin_amdgcn_s_waitcnt(0x0F70);
-                    if (__builtin_expect(dl_stage == 2, 1)) dl_compute(std::bool_constant<(HK > 0)>{});
+                    if (__builtin_expect(dl_stage == 2, 1)) {
+                        dl_compute(std::bool_constant<(HK > 0)>{});
+                        // the loss leg of the DiffDelGRU step: the ESR terms of the tile whose y has just been formed
+                        if constexpr (ESR_DL) esr_accumulate(dl_tile, dl_out, std::bool_constant<(HK > 0)>{});
+                    }
                 }
                 // the x loads go out before the flush's stores (no VMEM drain between them)
                 f32x4 fv = {0.0f, 0.0f, 0.0f, 0.0f};
-                if constexpr (ESR) {
+                if constexpr (ESR_FLUSH) {
                     // the flushed tile's sums and its ESR terms first: they consume the target fetched one tile ago, and
                     // nothing newer may be in flight when hipcc waits for it (it waits for everything)
                     __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -624,7 +630,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 #else
                 if (__builtin_expect((tile + 1) * TT < T, 1)) load_x_tile(tile + 1, xr);
 #endif
-                if constexpr (ESR) {
+                if constexpr (ESR_FLUSH) {
                     // the next flush's target (tile next_flush + 1 = this tile when t > 65): whole inside the unrolled loop
                     if (__builtin_expect(t > 65, 1)) {
                         if (HK > 0) esr_fetch_whole(next_flush + 1);
@@ -633,10 +639,15 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
                     }
                 }
                 if constexpr (FUSE) {
-                    if (__builtin_expect(dl_on && t > 65, 1)) dl_load_d((int)next_flush, std::bool_constant<(HK > 0)>{});
+                    if (__builtin_expect(dl_on && t > 65, 1)) {
+                        dl_load_d((int)next_flush, std::bool_constant<(HK > 0)>{});
+                        if constexpr (ESR_DL) {
+                            if (HK > 0) esr_fetch_whole(next_flush);       // the target of the delay tile now in flight
+                        }
+                    }
                     dl_store();
                 }
-                if constexpr (!ESR) {
+                if constexpr (!ESR_FLUSH) {
                     if (__builtin_expect(t > 65, 1)) { flush_y_tile(next_flush, std::bool_constant<(HK > 0)>{}); ++next_flush; }
                 }
             } else if (HK == 2 || (HK < 0 && ph == 34)) {
@@ -766,6 +777,30 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     // ---- epilogue: remaining y tiles, final state ---------------------------------------------------
     __syncthreads();
     while (next_flush * TT < T) { flush_y_tile(next_flush, std::false_type{}); ++next_flush; }
+    if constexpr (FUSE) {
+        if (dl_on) {
+            // every pre_d tile is stored: make the stores visible to the workgroup, then run the delay tiles that are left
+            // (the one in flight first) back to back -- at most two tiles plus the ragged tail per launch
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int next_delay = 0;
+            if (dl_stage == 1) dl_issue_taps(std::false_type{});
+            if (dl_stage == 2) {
+                next_delay = dl_tile + 1;
+                dl_compute(std::false_type{});
+                if constexpr (ESR_DL) esr_accumulate(dl_tile, dl_out, std::false_type{});
+                dl_store();
+            }
+            for (; (int64_t)next_delay * TT < T; ++next_delay) {
+                dl_load_d(next_delay, std::false_type{});
+                dl_issue_taps(std::false_type{});
+                dl_compute(std::false_type{});
+                if constexpr (ESR_DL) esr_accumulate(next_delay, dl_out, std::false_type{});
+                dl_store();
+            }
+            if (a.dl_flag && __any(dl_bad) && l == 0) atomicOr(a.dl_flag, 1);
+        }
+    }
     if constexpr (ESR) {
         // the 16 threads of a stream (one lane group of 16) add their columns in a fixed butterfly order
 #pragma unroll
@@ -776,24 +811,6 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         if (y_row_ok && (tid & 15) == 0) {
             a.esr_out[(s0 + (tid >> 4)) * 2 + 0] = esr_e;
             a.esr_out[(s0 + (tid >> 4)) * 2 + 1] = esr_t;
-        }
-    }
-    if constexpr (FUSE) {
-        if (dl_on) {
-            // every pre_d tile is stored: make the stores visible to the workgroup, then run the delay tiles that are left
-            // (the one in flight first) back to back -- at most two tiles plus the ragged tail per launch
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            int next_delay = 0;
-            if (dl_stage == 1) dl_issue_taps(std::false_type{});
-            if (dl_stage == 2) { next_delay = dl_tile + 1; dl_compute(std::false_type{}); dl_store(); }
-            for (; (int64_t)next_delay * TT < T; ++next_delay) {
-                dl_load_d(next_delay, std::false_type{});
-                dl_issue_taps(std::false_type{});
-                dl_compute(std::false_type{});
-                dl_store();
-            }
-            if (a.dl_flag && __any(dl_bad) && l == 0) atomicOr(a.dl_flag, 1);
         }
     }
 
@@ -868,6 +885,11 @@ hipError_t launch_gru_mfma2_fused(const GruArgs &a, hipStream_t stream)
     if (a.T >= (1LL << 26) || a.ys != a.T) return hipErrorInvalidValue;   // contiguous rows; 32-bit BYTE offsets inside a 16-row block
     const unsigned grid = (unsigned)((a.B + m2::SG - 1) / m2::SG);
     const bool many = grid > (unsigned)device_cus();
+    if (a.tgt) {        // + the ESR sums of the delayed output against a target, in the fused delay stage
+        if (!a.esr_out || (a.esr_skip & 3) || a.esr_skip < 0 || a.warmup) return hipErrorInvalidValue;
+        return many ? NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 4, true, true>), smem4)
+                    : NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 16, true, true>), smem16);
+    }
     return many ? NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 4, true>), smem4)
                 : NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 16, true>), smem16);
 }

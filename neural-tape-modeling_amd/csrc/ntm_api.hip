@@ -164,11 +164,14 @@ int ntm_delay_forward(const float *x, const float *d, float *y, int64_t B, int64
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_delay_forward");
 }
 
-int ntm_diffdel_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
-                               const float *w_o, int H, const float *x, const float *d, float *y, float *pre_d,
-                               int64_t B, int64_t T, float *h_state, float *dl_state, int D, int warmup,
-                               int32_t *err_flag, int mode, void *stream)
+static int diffdel_impl(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *w_o, int H,
+                        const float *x, const float *d, float *y, float *pre_d, int64_t B, int64_t T, float *h_state,
+                        float *dl_state, int D, int warmup, int32_t *err_flag, int mode, const float *target, int64_t skip,
+                        double *esr_out, void *stream)
 {
+    // target != NULL: also the per-stream ESR sums of y against target over [skip, T) (ntm_diffdel_gru_forward_esr): inside the
+    // fused launch where it runs and skip is a multiple of 4, by the streaming pass (one row per stream) everywhere else
+    const bool esr_in_kernel = target && (skip & 3) == 0 && !warmup;
     if (!pre_d || pre_d == y) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: pre_d must be a distinct buffer");
     if (mode != NTM_DIFFDEL_AUTO && mode != NTM_DIFFDEL_TWO_PASS && mode != NTM_DIFFDEL_FUSED)
         return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: unknown mode");
@@ -201,6 +204,11 @@ int ntm_diffdel_gru_forward_ex(const float *w_ih, const float *w_hh, const float
         a.dl_flag = err_flag;
         a.D = D;
         a.warmup = warmup;
+        if (esr_in_kernel) {
+            a.tgt = target;
+            a.esr_out = esr_out;
+            a.esr_skip = skip;
+        }
         hipError_t e = ntm::launch_gru_mfma2_fused(a, (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "ntm_diffdel_gru_forward");
     }
@@ -211,14 +219,48 @@ int ntm_diffdel_gru_forward_ex(const float *w_ih, const float *w_hh, const float
         if (rc != NTM_OK) return rc;
         if (r <= 0 || T <= 0) return NTM_OK;
         if (!d || !y || (D > 0 && !dl_state)) return fail(NTM_EINVAL, "ntm_delay_forward: null pointer");
-        if (fused == 0) return ntm_delay_forward(pre_d, d, y, B, T, dl_state, D, warmup, err_flag, stream);
+        if (fused == 0) {
+            rc = ntm_delay_forward(pre_d, d, y, B, T, dl_state, D, warmup, err_flag, stream);
+            if (rc != NTM_OK || !target) return rc;
+            hipError_t ee = ntm::launch_esr(y, target, B, T, skip, 1, esr_out, (hipStream_t)stream);
+            return ee == hipSuccess ? NTM_OK : hip_fail(ee, "ntm_diffdel_gru_forward_esr");
+        }
         // mixed: interpolate the remainder here, then ONE buffer update over all streams (it reads the flag both parts raise)
         hipError_t e = ntm::launch_delay_apply(pre_d + o, d + o, y + o, r, T, dl_state ? dl_state + fused * D : nullptr, D, warmup,
                                                err_flag, (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "ntm_diffdel_gru_forward");
     }
     hipError_t e = ntm::launch_delay_update(pre_d, B, T, dl_state, D, err_flag, (hipStream_t)stream);
-    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_diffdel_gru_forward");
+    if (e != hipSuccess) return hip_fail(e, "ntm_diffdel_gru_forward");
+    if (target) {               // the streams whose sums did not ride in the fused launch
+        const int64_t from = esr_in_kernel ? fused : 0;
+        if (from < B) {
+            e = ntm::launch_esr(y + from * T, target + from * T, B - from, T, skip, 1, esr_out + 2 * from, (hipStream_t)stream);
+            if (e != hipSuccess) return hip_fail(e, "ntm_diffdel_gru_forward_esr");
+        }
+    }
+    return NTM_OK;
+}
+
+int ntm_diffdel_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                               const float *w_o, int H, const float *x, const float *d, float *y, float *pre_d,
+                               int64_t B, int64_t T, float *h_state, float *dl_state, int D, int warmup,
+                               int32_t *err_flag, int mode, void *stream)
+{
+    return diffdel_impl(w_ih, w_hh, b_ih, b_hh, w_o, H, x, d, y, pre_d, B, T, h_state, dl_state, D, warmup, err_flag, mode, nullptr, 0,
+                        nullptr, stream);
+}
+
+int ntm_diffdel_gru_forward_esr(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                                const float *w_o, int H, const float *x, const float *d, float *y, float *pre_d,
+                                int64_t B, int64_t T, float *h_state, float *dl_state, int D, int32_t *err_flag,
+                                const float *target, int64_t skip, double *esr_out, void *stream)
+{
+    if (!target || !esr_out) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward_esr: null pointer");
+    if (skip < 0 || skip > T) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward_esr: bad skip");
+    if (target == y || target == pre_d) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward_esr: target must not alias an output");
+    return diffdel_impl(w_ih, w_hh, b_ih, b_hh, w_o, H, x, d, y, pre_d, B, T, h_state, dl_state, D, 0, err_flag, NTM_DIFFDEL_AUTO, target,
+                        skip, esr_out, stream);
 }
 
 int ntm_diffdel_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,

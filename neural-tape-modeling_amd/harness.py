@@ -39,8 +39,7 @@ def compute_loss(model, input, target, d_traj=None, INIT_LEN=1024):
     rank (its shard of the segments); d_traj (B,1,T) in samples for DiffDelGRU.
     Returns the job-wide dict of distributed.reduce_loss_sums plus this rank's output tensor."""
     if isinstance(model, DiffDelRNN):
-        output, _ = model.predict(input, d_traj)
-        s = esr_sums(output, target, skip=INIT_LEN)               # cut first INIT_LEN samples (:367-369)
+        output, _, s = model.predict_esr(input, d_traj, target, skip=INIT_LEN)   # cut first INIT_LEN samples (:367-369)
     else:
         output, s = model.predict_esr(input, target, skip=INIT_LEN)     # the ESR sums ride in the recurrent launch
     n = input.shape[-1] - INIT_LEN

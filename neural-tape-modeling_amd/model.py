@@ -436,7 +436,43 @@ class DiffDelRNN(_GRUHead):
             _events[2].record()
         return y.view(B, 1, T), pre.view(B, 1, T)
 
-    def _fused_step(self, xbt, dbt, warmup, _events=None):
+    @torch.no_grad()
+    def forward_esr(self, x, del_traj, target, skip=0):
+        """forward(x, del_traj) AND the per-stream ESR sums of the delayed output against `target` over samples [skip, T)
+        (`model(input, d_traj)` followed by the ESR entry of the loss loop, code/test-model.py:353, :386-388) in one call:
+        (y, pre_d, sums (N,2) fp64).  ONE launch where the fused step runs (`delay_mode` / `kernel_variant` "auto", no skip
+        connection): the sums are accumulated in the fused delay stage; otherwise forward() + esr_sums()."""
+        xbt = _as_bt(x, "DiffDelRNN.forward_esr")
+        dbt = _as_bt(del_traj, "DiffDelRNN.forward_esr")
+        tbt = _as_bt(target, "DiffDelRNN.forward_esr")
+        if dbt.shape != xbt.shape or tbt.shape != xbt.shape:
+            raise RuntimeError(f"shape mismatch: x {tuple(x.shape)} vs del_traj {tuple(del_traj.shape)} vs target {tuple(target.shape)}")
+        if self.kernel_variant != "auto" or self.skip or self.delay_mode != "auto":
+            y, pre = self.forward(x, del_traj)
+            return y, pre, esr_sums(y, target, skip)
+        B, T = xbt.shape
+        y, pre, sums = self._fused_step(xbt, dbt, False, None, tbt, int(skip))
+        return y.view(B, 1, T), pre.view(B, 1, T), sums
+
+    @torch.no_grad()
+    def predict_esr(self, input, d_traj, target, skip=0):
+        """predict(input, d_traj) + the ESR sums of the output against `target` over [skip, T)."""
+        B = input.shape[0]
+        self.initialize_hidden(1, self.max_delay)
+        self.warm_start()
+        if B != 1:
+            self.hidden = self.hidden.expand(1, B, self.hidden_size).contiguous()
+            self.diffdel.buffer = self.diffdel.buffer.expand(B, 1, -1).contiguous()
+        deferred, self.diffdel.defer_check = self.diffdel.defer_check, True
+        try:
+            out = self.forward_esr(input, d_traj, target, skip)
+        finally:
+            self.diffdel.defer_check = deferred
+        if not deferred:
+            self.diffdel.raise_if_violated()
+        return out
+
+    def _fused_step(self, xbt, dbt, warmup, _events=None, tbt=None, skip=0):
         """One C-ABI call for GRU + head + delay line (ntm_diffdel_gru_forward_ex); carries self.hidden and the delay
         buffer exactly as the two calls do."""
         B, T = xbt.shape
@@ -455,10 +491,18 @@ class DiffDelRNN(_GRUHead):
         g = self.GRU
         if _events:
             _events[0].record()
-        rc = _lib.lib().ntm_diffdel_gru_forward_ex(
-            ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0), ptr(self.output.weight),
-            self.hidden_size, ptr(xbt), ptr(dbt), ptr(y), ptr(pre), B, T, ptr(h), ptr(dl.buffer), D, int(bool(warmup)),
-            ptr(dl._err), _lib.DIFFDEL_MODES[self.delay_mode], _lib.current_stream())
+        sums = None
+        if tbt is None:
+            rc = _lib.lib().ntm_diffdel_gru_forward_ex(
+                ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0), ptr(self.output.weight),
+                self.hidden_size, ptr(xbt), ptr(dbt), ptr(y), ptr(pre), B, T, ptr(h), ptr(dl.buffer), D, int(bool(warmup)),
+                ptr(dl._err), _lib.DIFFDEL_MODES[self.delay_mode], _lib.current_stream())
+        else:
+            sums = torch.empty(B, 2, device=xbt.device, dtype=torch.float64)
+            rc = _lib.lib().ntm_diffdel_gru_forward_esr(
+                ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0), ptr(self.output.weight),
+                self.hidden_size, ptr(xbt), ptr(dbt), ptr(y), ptr(pre), B, T, ptr(h), ptr(dl.buffer), D, ptr(dl._err),
+                ptr(tbt), int(skip), ptr(sums), _lib.current_stream())
         _lib.check(rc, "ntm_diffdel_gru_forward")
         if _events:
             _events[1].record()
@@ -468,7 +512,7 @@ class DiffDelRNN(_GRUHead):
             dl.raise_if_violated()
         else:
             dl._unchecked = True
-        return y, pre
+        return (y, pre) if tbt is None else (y, pre, sums)
 
     @torch.no_grad()
     def predict(self, input, d_traj, segment_length=None, _events=None):

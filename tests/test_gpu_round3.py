@@ -654,3 +654,59 @@ def test_forward_esr_raw_entry_point_and_predict_esr(ntm):
     assert L.ntm_gru_forward_esr(*args(p(yv), 0, p(out))) == -1 and b"alias" in L.ntm_last_error()
     assert L.ntm_gru_forward_esr(*args(p(t2), -4, p(out))) == -1
     assert L.ntm_gru_forward_esr(*args(None, 0, p(out))) == -1 and L.ntm_gru_forward_esr(*args(p(t2), 0, None)) == -1
+
+
+@pytest.mark.parametrize("B,T,D,skip", [(1040, 64, 37, 0), (1100, 333, 64, 128), (2050, 2000, 301, 1024), (5136, 900, 128, 64),
+                                       (4096 + 40, 700, 301, 256), (1040, 130, 37, 6), (24, 500, 64, 64), (1, 70, 5, 0)])
+def test_diffdel_forward_esr_equals_forward_plus_esr_pass(ntm, B, T, D, skip):
+    """DiffDelRNN.forward_esr / ntm_diffdel_gru_forward_esr (the loss leg accumulated in the fused delay stage, on the DELAYED
+    output) against forward() + the streaming ESR pass: y, pre_d and the carried state bit for bit, the sums to fp64 summation
+    order and against the oracle; trajectories with history taps, general-form lanes and ragged tails; a skip that is not a
+    multiple of 4, small batches, the many-groups build and a remainder behind a device round."""
+    rng = np.random.default_rng(3 * B + 5 * T + D + skip)
+    x = rng.uniform(-0.5, 0.5, (B, 1, T)).astype(np.float32)
+    d = _trajectories(rng, B, T, D)
+    t = (0.3 * np.tanh(2 * x) + 0.02 * rng.standard_normal(x.shape)).astype(np.float32)
+    h0 = rng.uniform(-0.3, 0.3, (1, B, 64)).astype(np.float32)
+    b0 = rng.uniform(-0.3, 0.3, (B, 1, D)).astype(np.float32)
+    out = {}
+    for fused in (True, False):
+        m = _ddr(ntm, D - 1, "auto")
+        m.initialize_hidden(B, D - 1)
+        m.hidden, m.diffdel.buffer = dev(h0), dev(b0)
+        if fused:
+            y, pre, s = m.forward_esr(dev(x), dev(d).unsqueeze(1), dev(t), skip)
+        else:
+            y, pre = m.forward(dev(x), dev(d).unsqueeze(1))
+            s = ntm.model.esr_sums(y, dev(t), skip)
+        out[fused] = (y, pre, m.hidden.clone(), m.diffdel.buffer.clone(), s)
+    for a, b in zip(out[True][:4], out[False][:4]):
+        assert torch.equal(a, b)
+    sa, sb = out[True][4].cpu().numpy(), out[False][4].cpu().numpy()
+    assert sa.shape == (B, 2) and np.abs(sa - sb).max() <= 1e-12 * max(1.0, np.abs(sb).max())
+    rows = sorted({0, B // 2, B - 1})
+    so = oracle.esr_sums(out[True][0][rows, 0].cpu().numpy(), t[rows, 0], skip)
+    assert np.abs(sa[rows] - so).max() <= 1e-9 * max(1.0, np.abs(so).max())
+
+
+def test_diffdel_predict_esr_and_compute_loss(ntm):
+    """predict_esr on golden g5 repeated over a batch (the reference's own DiffDelGRU output as target: ESR ~ 0), the deferred
+    range check still raises, and harness.compute_loss (code/test-model.py:332-398) gives the ESR of predict() + esr_sums."""
+    g = load("g5_diffdel_predict.npz")
+    B = 1056
+    x, d, tgt = dev(np.repeat(g["x"], B, 0)), dev(np.repeat(g["d"], B, 0)), dev(np.repeat(g["y"], B, 0))
+    m = _ddr(ntm, int(g["max_delay"]), "auto")
+    y, pre, s = m.predict_esr(x, d, tgt, skip=1024)
+    y2, pre2 = m.predict(x, d)
+    assert torch.equal(y, y2) and torch.equal(pre, pre2)
+    n = x.shape[-1] - 1024
+    esr = ((s[:, 0] / n) / (s[:, 1] / n + ntm.model.ESR_EPS)).cpu().numpy()
+    assert esr.max() < 1e-8
+    bad = d.clone()
+    bad[7, 0, 3000] = int(g["D_effective"]) + 2.0
+    with pytest.raises(AssertionError):
+        m.predict_esr(x, bad, tgt, skip=1024)
+    res, out = ntm.harness.compute_loss(m, x, tgt, d_traj=d, INIT_LEN=1024)
+    s_ref = ntm.model.esr_sums(y2, tgt, 1024)
+    want = float(((s_ref[:, 0] / n) / (s_ref[:, 1] / n + ntm.model.ESR_EPS)).mean())
+    assert abs(res["ESR"] - want) <= 1e-12 + 1e-9 * want and torch.equal(out, y2)
