@@ -115,6 +115,10 @@ int ntm_gru_forward_esr(const float *w_ih, const float *w_hh, const float *b_ih,
     if (B < 0 || T < 0 || skip < 0 || skip > T) return fail(NTM_EINVAL, "ntm_gru_forward_esr: bad size");
     if (B == 0) return NTM_OK;
     if (!target || !esr_out) return fail(NTM_EINVAL, "ntm_gru_forward_esr: null pointer");
+    if (T == 0) {                                // no samples: the sums are zero
+        hipError_t ez = hipMemsetAsync(esr_out, 0, (size_t)B * 2 * sizeof(double), (hipStream_t)stream);
+        return ez == hipSuccess ? NTM_OK : hip_fail(ez, "ntm_gru_forward_esr");
+    }
     if (target == y) return fail(NTM_EINVAL, "ntm_gru_forward_esr: target must not alias y");
     // streams the matrix-pipe kernel takes (as ntm_gru_forward's NTM_GRU_AUTO decides): there the sums ride in the launch
     int64_t fused = 0;
@@ -172,6 +176,10 @@ static int diffdel_impl(const float *w_ih, const float *w_hh, const float *b_ih,
     // target != NULL: also the per-stream ESR sums of y against target over [skip, T) (ntm_diffdel_gru_forward_esr): inside the
     // fused launch where it runs and skip is a multiple of 4, by the streaming pass (one row per stream) everywhere else
     const bool esr_in_kernel = target && (skip & 3) == 0 && !warmup;
+    if (target && B > 0 && T == 0) {            // no samples: the sums are zero
+        hipError_t ez = hipMemsetAsync(esr_out, 0, (size_t)B * 2 * sizeof(double), (hipStream_t)stream);
+        if (ez != hipSuccess) return hip_fail(ez, "ntm_diffdel_gru_forward_esr");
+    }
     if (!pre_d || pre_d == y) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: pre_d must be a distinct buffer");
     if (mode != NTM_DIFFDEL_AUTO && mode != NTM_DIFFDEL_TWO_PASS && mode != NTM_DIFFDEL_FUSED)
         return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: unknown mode");
