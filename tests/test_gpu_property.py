@@ -236,3 +236,48 @@ def test_fused_diffdel_step_random_shapes_bit_identical_to_two_pass(ntm, B, T, D
         assert torch.equal(a, b), what
     yo, bo = oracle.delay_forward(res["fused"][1].cpu().numpy(), d, b0)
     assert np.array_equal(res["fused"][0].cpu().numpy(), yo) and np.array_equal(res["fused"][3][:, 0].cpu().numpy(), bo)
+
+
+# ----------------------------------------------------------------------------- the loss leg inside the launch (round 3)
+@settings(max_examples=40, **SET)
+@given(B=st.sampled_from([1, 17, 1030, 1100, 2070]), T=st.integers(1, 900), skip4=st.integers(0, 230), odd=st.booleans(),
+       seed=st.integers(0, 2**31 - 1), diffdel=st.booleans())
+def test_forward_esr_random_shapes(ntm, B, T, skip4, odd, seed, diffdel):
+    """RNN.forward_esr / DiffDelRNN.forward_esr on random shapes and skips (multiples of 4: inside the launch where the
+    matrix-pipe kernel runs; odd ones and small batches: forward + streaming pass): outputs and state bit-identical to
+    forward(), sums equal to esr_sums() of that output to fp64 summation order."""
+    rng = np.random.default_rng(seed)
+    skip = min(T, 4 * skip4 + (1 if odd else 0))
+    x = dev(rng.uniform(-0.5, 0.5, (B, 1, T)).astype(np.float32))
+    t = dev(rng.uniform(-0.5, 0.5, (B, 1, T)).astype(np.float32))
+    h0 = dev(rng.uniform(-0.3, 0.3, (1, B, 64)).astype(np.float32))
+    if diffdel:
+        D = 64
+        d = dev(np.clip(30 + 25 * np.sin(np.arange(T)[None, None, :] / rng.uniform(5, 90, (B, 1, 1))), 0, D).astype(np.float32))
+        b0 = dev(rng.uniform(-0.3, 0.3, (B, 1, D)).astype(np.float32))
+        res = []
+        for fused in (True, False):
+            m = ntm.DiffDelRNN(1, 64, 1, max_delay=D - 1)
+            m.load_state_dict(ntm.weights.load_state_dict(ntm.weights.W_DIFFDEL))
+            m = m.to("cuda").eval()
+            m.initialize_hidden(B, D - 1)
+            m.hidden, m.diffdel.buffer = h0.clone(), b0.clone()
+            if fused:
+                y, pre, s = m.forward_esr(x, d, t, skip)
+            else:
+                y, pre = m.forward(x, d)
+                s = ntm.model.esr_sums(y, t, skip)
+            res.append((y, pre, m.hidden, m.diffdel.buffer, s))
+        for a, b in zip(res[0][:4], res[1][:4]):
+            assert torch.equal(a, b)
+        sa, sb = res[0][4].cpu().numpy(), res[1][4].cpu().numpy()
+    else:
+        m = ntm.harness.build_model(ntm.weights.W_GRU)
+        m.hidden = h0.clone()
+        y1, s1 = m.forward_esr(x, t, skip)
+        h1 = m.hidden.clone()
+        m.hidden = h0.clone()
+        y2 = m.forward(x)
+        assert torch.equal(y1, y2) and torch.equal(h1, m.hidden)
+        sa, sb = s1.cpu().numpy(), ntm.model.esr_sums(y2, t, skip).cpu().numpy()
+    assert np.abs(sa - sb).max() <= 1e-12 * max(1.0, np.abs(sb).max())

@@ -151,12 +151,39 @@ int main(int argc, char **argv)
     if (rc != NTM_OK) { fprintf(stderr, "ntm_gru_forward: %d %s\n", rc, ntm_last_error()); return 5; }
     // error path: a hidden size that is not compiled (8, 16, 32, 64 are) must be refused with a message, not crash
     if (ntm_gru_forward(w_ih, w_hh, b_ih, b_hh, w_o, b_o, 24, dx, dy, B, T, T, T, dh, stream) == NTM_OK) return 6;
+    // forward + the ESR sums of the loss loop in ONE call (ntm_gru_forward_esr; target = the input here), against the
+    // streaming pass on the same output: the sums agree to fp64 summation order
+    double *e1, *e2;
+    const int splits = ntm_esr_splits(B, T, 0);
+    HIP_OK(hipMalloc(&e1, (size_t)B * 2 * sizeof(double)));
+    HIP_OK(hipMalloc(&e2, (size_t)B * splits * 2 * sizeof(double)));
+    float *dy2, *dh2;
+    HIP_OK(hipMalloc(&dy2, x.size() * sizeof(float)));
+    HIP_OK(hipMalloc(&dh2, (size_t)B * 64 * sizeof(float)));
+    HIP_OK(hipMemset(dh2, 0, (size_t)B * 64 * sizeof(float)));
+    if (ntm_gru_forward_esr(w_ih, w_hh, b_ih, b_hh, w_o, b_o, NTM_HIDDEN, dx, dy2, B, T, T, T, dh2, dx, 0, e1, stream) != NTM_OK) {
+        fprintf(stderr, "ntm_gru_forward_esr: %s\n", ntm_last_error()); return 7;
+    }
+    if (ntm_esr_sums(dy2, dx, B, T, 0, splits, e2, stream) != NTM_OK) return 8;
+    HIP_OK(hipStreamSynchronize(stream));
+    std::vector<double> v1((size_t)B * 2), v2((size_t)B * splits * 2);
+    HIP_OK(hipMemcpy(v1.data(), e1, v1.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(v2.data(), e2, v2.size() * sizeof(double), hipMemcpyDeviceToHost));
+    double worst = 0.0;
+    for (long b = 0; b < B; ++b)
+        for (int c = 0; c < 2; ++c) {
+            double ref = 0.0;
+            for (int p = 0; p < splits; ++p) ref += v2[(b * splits + p) * 2 + c];
+            const double rel = ref != 0.0 ? (v1[b * 2 + c] - ref) / ref : v1[b * 2 + c];
+            worst = rel < 0 ? (-rel > worst ? -rel : worst) : (rel > worst ? rel : worst);
+        }
+    if (worst > 1e-12) { fprintf(stderr, "ntm_gru_forward_esr sums differ from ntm_esr_sums: %g\n", worst); return 9; }
     HIP_OK(hipStreamSynchronize(stream));
     std::vector<float> y(x.size()), h((size_t)B * 64);
     HIP_OK(hipMemcpy(y.data(), dy, y.size() * sizeof(float), hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(h.data(), dh, h.size() * sizeof(float), hipMemcpyDeviceToHost));
     FILE *f = fopen(argv[5], "wb"); fwrite(y.data(), sizeof(float), y.size(), f); fclose(f);
     f = fopen(argv[6], "wb"); fwrite(h.data(), sizeof(float), h.size(), f); fclose(f);
-    printf("ok B=%ld T=%ld last_error_after_refusal=\"%s\"\n", B, T, ntm_last_error());
+    printf("ok B=%ld T=%ld forward_esr_vs_esr_sums_rel=%.1e last_error_after_refusal=\"%s\"\n", B, T, worst, ntm_last_error());
     return 0;
 }
