@@ -16,7 +16,10 @@ segment (code/dataset.py:262-279) and, with `demodulate=True`, demodulates the t
 (code/dataset.py:395-408).
 Stereo pairs without a side-car are analysed on first use like the reference does (`find_pulses` / `analyze_delay`
 below = code/utilities/utilities.py:343-406, :466-610, pinned by golden g12) and the side-car is written.
-What is NOT kept (out of scope): fractional sub-sampling, shuffling, half/double storage.
+`fraction` / `shuffle` select the examples as `create_fractional_patches` does (code/dataset.py:295-341, one device
+configuration): the first `int(len * fraction)` segments, or with `shuffle=True` that many drawn WITH replacement by
+`np.random.randint` (the reference's global, unseeded generator; `seed` makes the draw repeatable here).
+What is NOT kept (out of scope): half/double storage, un-preloaded operation.
 The dataset itself (Zenodo 8026272) is not available here, so this module is checked against synthetic
 files only (tests/test_feeder.py).
 """
@@ -184,7 +187,7 @@ def demodulate(output, x_idx_pulse, y_idx_pulse):
 
 class SegmentFeeder:
     def __init__(self, data_dir, subset="train", length=44100, input_only=False, sync=0.0, demodulate=False,
-                 analyze=True, write_sidecars=True):
+                 analyze=True, write_sidecars=True, fraction=1.0, shuffle=False, seed=None):
         assert os.path.exists(data_dir), "Can't find chosen data_dir"
         assert not (input_only and demodulate), "Can't demodulate without inputs"       # code/dataset.py:68
         self.data_dir, self.subset, self.length, self.input_only, self.sync = data_dir, subset, length, input_only, sync
@@ -250,6 +253,17 @@ class SegmentFeeder:
         n_traj = sum(1 for a in self._audio if a[2] is not None)
         self.mean_delay = self.mean_delay / n_traj if n_traj else 0.0               # utilities.py:341
         assert not (demodulate and n_traj != len(self._audio)), "Can't demodulate without trajectory side-cars!"
+        # code/dataset.py:295-341 (create_fractional_patches, a single class of examples)
+        self.fraction, self.shuffle = fraction, shuffle
+        n_use = int(len(self.examples) * fraction)
+        if n_use <= 0:
+            raise ValueError(f"Fraction `{fraction}` set too low. No examples selected.")
+        if shuffle:
+            rs = np.random if seed is None else np.random.RandomState(seed)
+            pick = rs.randint(0, high=len(self.examples), size=n_use)
+        else:
+            pick = np.arange(n_use)
+        self.examples = [self.examples[i] for i in pick]
         self.minutes = self.length * len(self.examples) / self.fs / 60
 
     @staticmethod

@@ -534,8 +534,8 @@ def test_cli_loss_over_synthetic_dataset(ntm, tmp_path):
     assert len(f) == 6
     # default INIT_LEN: the reference's nextpow2(int(0 * fs)) == 2 for a dataset without delay (code/test-model.py:323-324)
     for init, extra in ((2, []), (1024, ["--INIT_LEN", "1024"])):
-        got = cli.main(["--DATASET_DIR", str(tmp_path / "ToySet"), "--WEIGHTS", W_G, "--SEGMENT_LENGTH", str(L),
-                        "--BATCH_SIZE", "4", "--COMPUTE_LOSS"] + extra)
+        got = cli.main(["--DATASET_DIR", str(tmp_path / "ToySet"), "--SUBSET", "Test", "--WEIGHTS", W_G, "--SEGMENT_LENGTH", str(L),
+                        "--BATCH_SIZE", "4", "--COMPUTE_LOSS", "--NO_SHUFFLE", "--TEMP_PATH", str(tmp_path / f"t{init}")] + extra)
         want = float(np.mean(oracle.esr_per_segment(yo, Tg, init)))
         sd = oracle.esr_dcpre_sums(yo, Tg, init); n = L - init
         want_dc = float(np.mean((sd[:, 0] / n) / (sd[:, 1] / n + 1e-5)))
@@ -773,7 +773,8 @@ def test_cli_diffdel_on_raw_stereo_dataset(ntm, tmp_path):
     wavfile.write(str(d / "input_0_.wav"), fs, np.stack([audio, g["in0"]], 1))
     wavfile.write(str(d / "target_0_.wav"), fs, np.stack([tgt_audio, g["out0"]], 1))
     L = 11000
-    got = cli.main(["--DATASET_DIR", str(tmp_path / "Wow"), "--WEIGHTS", W_D, "--SEGMENT_LENGTH", str(L), "--COMPUTE_LOSS"])
+    got = cli.main(["--MODEL", "DiffDelGRU", "--DATASET_DIR", str(tmp_path / "Wow"), "--SUBSET", "Test", "--NO_SHUFFLE", "--WEIGHTS", W_D,
+                    "--SEGMENT_LENGTH", str(L), "--COMPUTE_LOSS", "--TEMP_PATH", str(tmp_path / "tmp")])
     # expected, from the reference's own analysis result (golden g12) and the oracle
     T = g["T0"]
     max_delay_n = int(1.25 * T.max() * fs)
@@ -806,8 +807,8 @@ def test_cli_add_delay_mode(ntm, tmp_path):
     wavfile.write(str(d / "input_0_.wav"), fs, np.stack([audio, g["in1"]], 1))
     wavfile.write(str(d / "target_0_.wav"), fs, np.stack([tgt_audio, g["out1"]], 1))
     L = 14000
-    got = cli.main(["--DATASET_DIR", str(tmp_path / "Wow"), "--WEIGHTS", W_G, "--SEGMENT_LENGTH", str(L), "--COMPUTE_LOSS",
-                    "--ADD_DELAY"])
+    got = cli.main(["--DATASET_DIR", str(tmp_path / "Wow"), "--SUBSET", "Test", "--NO_SHUFFLE", "--WEIGHTS", W_G, "--SEGMENT_LENGTH", str(L),
+                    "--COMPUTE_LOSS", "--ADD_DELAY", "--TEMP_PATH", str(tmp_path / "tmp")])
     T = g["T1"]
     D = int(1.25 * T.max() * fs)
     init = 1 << (int(T.max() * fs) - 1).bit_length()

@@ -413,11 +413,12 @@ def test_cli_two_ranks_one_segment_does_not_hang(tmp_path):
     x = rng.uniform(-0.4, 0.4, 6000).astype(np.float32)
     wavfile.write(str(d / "input_1_.wav"), 44100, x)
     wavfile.write(str(d / "target_1_.wav"), 44100, (0.5 * x).astype(np.float32))
-    args = [sys.executable, os.path.join(ROOT, "tools", "test_model.py"), "--DATASET_DIR", str(tmp_path / "One"), "--WEIGHTS", W_G,
+    args = [sys.executable, os.path.join(ROOT, "tools", "test_model.py"), "--DATASET_DIR", str(tmp_path / "One"), "--SUBSET", "Test", "--NO_SHUFFLE", "--WEIGHTS", W_G,
             "--COMPUTE_LOSS"]
     base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    one = subprocess.run(args, env=base, capture_output=True, text=True, timeout=300)
+    one = subprocess.run(args + ["--TEMP_PATH", str(tmp_path / "t1")], env=base, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
     assert one.returncode == 0, one.stderr[-2000:]
+    args += ["--TEMP_PATH", str(tmp_path / "t2")]
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -425,7 +426,7 @@ def test_cli_two_ranks_one_segment_does_not_hang(tmp_path):
     for rank in range(2):
         env = dict(base, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    NTM_DIST_BACKEND="gloo")
-        procs.append(subprocess.Popen(args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        procs.append(subprocess.Popen(args, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=str(tmp_path)))
     outs = [p.communicate(timeout=300) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     stats = lambda text: [ln for ln in text.splitlines() if ":" in ln and ln.split(":")[0].strip() in ("Segments", "ESR", "DCPreESR", "MultiSTFT")]  # noqa: E731

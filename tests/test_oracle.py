@@ -339,3 +339,61 @@ def test_g18_validate_batched_inference():
         assert np.abs(pre[0] - g["dd_pre_d"][k]).max() < 5e-6 and np.abs(y[0] - g["dd_pred"][k]).max() < 5e-6
     assert abs(tot / len(batches) - float(g["dd_val_loss"])) < 1e-5
     assert np.abs(h - g["dd_hidden"][0]).max() < 5e-6 and np.abs(buf - g["dd_buffer"][:, 0]).max() < 5e-6
+
+
+# ----------------------------------------------------------------------------- round 4: every shipped checkpoint, the harness' shapes
+def _bar(y, ref32, y64):
+    """tests/test_gpu_round4.py's bar: 1e-5 against the reference, or -- where the reference's own fp32 result is further
+    than 2e-6 from the fp64 evaluation of the same network -- as close to that fp64 truth as the reference is."""
+    d32 = float(np.abs(y - ref32).max())
+    s = float(np.abs(ref32.astype(np.float64) - y64).max())
+    ok = d32 < 1e-5 if s <= 2e-6 else (d32 < 1e-5 or float(np.abs(y - y64).max()) <= 2.0 * s)
+    return ok, d32, s
+
+
+def test_oracle_against_every_shipped_checkpoint_g19():
+    """The C restatement against the reference's predict() for all 32 distinct best.pth (44 names), GRU and DiffDelGRU at
+    the toy and the real-tape delay length; teacher-forced from the reference's warm state the 1e-5 bar holds for ALL of them."""
+    g = load("g19_checkpoints.npz")
+    names, nf = [str(n) for n in g["names"]], [str(f) for f in g["name_file"]]
+    assert len(names) == 44 and len(set(nf)) == 32
+    xl = (g["x_int16"].astype(np.float32) / 32768.0)[None]
+    T = int(g["T"])
+    self_noise = {}
+    for f in sorted(set(nf)):
+        name, k = names[nf.index(f)], f[:-4]
+        w = oracle_weights(name)
+        if name.startswith("GRU"):
+            y, _ = oracle.gru_predict(w, xl[:, :T])
+            ok, d32, s = _bar(y[0], g[k + "_y"], g[k + "_y64"].astype(np.float64))
+            assert ok, (name, d32, s)
+            self_noise[k] = s
+            yt, _ = oracle.gru_forward(w, xl[:, :T], h=g[k + "_hwarm"][None].copy())
+            assert np.abs(yt[0] - g[k + "_y"]).max() < 1e-5, name
+        else:
+            y, pre, _, _ = oracle.diffdel_predict(w, xl[:, :T], g["d_toy"][None], int(g["max_delay_toy"]))
+            assert _bar(y[0], g[k + "_y"], g[k + "_y64"].astype(np.float64))[0], name
+            assert _bar(pre[0], g[k + "_pre"], g[k + "_pre64"].astype(np.float64))[0], name
+            if k + "_y_real" in g.files:
+                y, pre, _, _ = oracle.diffdel_predict(w, xl, g["d_real"][None], int(g["max_delay_real"]))
+                assert _bar(y[0], g[k + "_y_real"], g[k + "_y64_real"].astype(np.float64))[0], name
+                assert _bar(pre[0], g[k + "_pre_real"], g[k + "_pre64_real"].astype(np.float64))[0], name
+    # GRU-...-L[DCPreESR]-DS[...CHOWTAPE]_1 (w19): its zero-input warm-up amplifies rounding -- the reference's fp32 predict
+    # is 1.5e-2 away from its own fp64 evaluation; every other GRU checkpoint reproduces itself to < 1e-5 on this input
+    assert self_noise.pop("w19") > 1e-3 and max(self_noise.values()) < 1e-5
+
+
+def test_oracle_at_the_harness_operating_point_g20():
+    g = load("g20_operating_point.npz")
+    x = (g["gru_x_int16"].astype(np.float32) / 32768.0)[None]
+    for tag in ("chow", "akai"):
+        y, _ = oracle.gru_predict(oracle_weights(str(g[f"gru_{tag}_weights"])), x)
+        ok, d32, s = _bar(y[0], g[f"gru_{tag}_y"], g[f"gru_{tag}_y64"].astype(np.float64))
+        assert ok, (tag, d32, s)
+        assert (tag == "chow") == (s <= 2e-6)      # the AKAI checkpoint drifts 2.9e-5 from its own fp64 evaluation inside 10 s
+    for tag in ("toy", "real"):
+        x = (g[f"dd_{tag}_x_int16"].astype(np.float32) / 32768.0)[None]
+        y, pre, h, buf = oracle.diffdel_predict(oracle_weights(str(g[f"dd_{tag}_weights"])), x, g[f"dd_{tag}_d"][None],
+                                               int(g[f"dd_{tag}_max_delay"]))
+        assert np.abs(y[0] - g[f"dd_{tag}_y"]).max() < 1e-5 and np.abs(pre[0] - g[f"dd_{tag}_pre"]).max() < 1e-5
+        assert np.abs(buf[0] - g[f"dd_{tag}_buffer"]).max() < 1e-5

@@ -1,19 +1,36 @@
 #!/usr/bin/env python3
-"""The `--COMPUTE_LOSS` path of the reference's evaluation CLI (code/test-model.py:45-85, 192-247, 296-418)
-on the MI355X engine: same UPPER_CASE flags where they apply, batched over segments, shardable over ranks.
+"""The reference's evaluation CLI (code/test-model.py) on the MI355X engine: the SAME command line --
 
-    python tools/test_model.py --DATASET_DIR <dir with Test/input_*.wav, target_*.wav> \
-        --WEIGHTS "GRU-HS[64]-L[DCPreESR]-DS[...]_BEST" --SEGMENT_LENGTH 441000 --BATCH_SIZE 64 --COMPUTE_LOSS
+    python -u tools/test_model.py --MODEL GRU --WEIGHTS "GRU-HS[64]-L[DCPreESR]-DS[...]_BEST" \
+        --DATASET ReelToReel_Dataset_MiniPulse100_CHOWTAPE_WOWFLUTTER --SUBSET Test --NO_SHUFFLE \
+        --SEGMENT_LENGTH 441000 --ADD_DELAY --COMPUTE_LOSS --SAVE_AUDIO --DESCRIPTIVE_NAME LOSS
 
-Differences: plotting / WAV export / noise are out of scope; delay trajectories (DiffDelGRU, `--DEMODULATE`, the
-dataset-derived INIT_LEN) come from the `trajectory_<id>_*.npy` side-cars, which the feeder computes and caches on
-first use for stereo datasets exactly as DelayAnalyzer does; mono datasets give `--MAX_DELAY` in seconds;
-`--WEIGHTS` names one of the exported checkpoints (ntm_amd.weights.available()) or a directory with best.pth.
+is scripts/test-model-loss.sh:57-63 verbatim.  Every flag of code/test-model.py:45-85 parses with the reference's type
+and default; what is built behind them is the part of the script that drives the model:
+
+  model construction from the weights-directory names   code/test-model.py:192-247   (all `--WEIGHTS`, nargs='+')
+  `--COMPUTE_LOSS`: loss over the dataset                code/test-model.py:296-418   (last model of `--WEIGHTS` and the
+                                                                                       `--MODEL` string, as upstream)
+  the example prediction on segment `--IDX`              code/test-model.py:420-552   (+ `--SAVE_AUDIO`, :876-893)
+
+batched over segments (`--BATCH_SIZE`, the reference loops with BATCH_SIZE = 1, :115) and shardable over ranks.
+Presentation and generator flags (`--SAVE_FIG --PLOT_* --ZOOM --ADD_NOISE --NOISE_TYPE --DATASET_NOISE`, `--DELAY_TYPE
+Generated`) are out of scope (matplotlib figures, the diffusion generators, the noise dataset): they parse and are
+reported in one "out of scope, ignored" line.
+
+Paths: `--DATASET <name>` is looked up under `--AUDIO_PATH` (default ../audio/, code/test-model.py:107,147) unless
+`--DATASET_DIR` names the directory itself; a `--WEIGHTS` entry is `<MODEL_PATH>/<name>/best.pth` when that exists
+(default ../weights/, :119,198-199,233), a directory holding best.pth, or one of the 44 exported checkpoints
+(ntm_amd.weights.available()).  Delay trajectories come from the `trajectory_<id>_*.npy` side-cars, which the feeder
+computes and caches on first use for stereo datasets exactly as DelayAnalyzer does; `--MAX_DELAY` (seconds) overrides
+the dataset's measured maximum.  Extra flags of this build: --DATASET_DIR --AUDIO_PATH --MODEL_PATH --RESULTS_PATH
+--TEMP_PATH --BATCH_SIZE --STREAM_CHUNK --MAX_DELAY --INIT_LEN --KERNEL --SEED --NO_EXAMPLE.
 """
 import argparse
 import os
 import sys
 
+import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,92 +38,306 @@ import ntm_amd  # noqa: E402
 from ntm_amd import distributed as D  # noqa: E402
 from ntm_amd.feeder import SegmentFeeder  # noqa: E402
 from ntm_amd.model import ESR_EPS, esr_dcpre_sums, esr_sums  # noqa: E402
+from ntm_amd.utilities import nextpow2, parse_hidden_size, parse_loss, parse_model  # noqa: E402
+
+OUT_OF_SCOPE = ("SAVE_FIG", "PLOT_SWEEP", "PLOT_TRANSFER", "PLOT_PHASE", "PLOT_DELAY", "ZOOM", "ADD_NOISE")
+MODEL_IDS = {                                            # code/test-model.py:206-212
+    'GRU-DCPreESR': 'Supervised 1',
+    'GRU-ESR': 'Supervised 1',
+    'DiffDelGRU-DCPreESR': 'Supervised 2',
+    'DiffDelGRU-ESR': 'Supervised 2',
+    'DiffDelGRU-LogSpec': 'Adversarial',
+}
 
 
-def main(argv=None):
-    p = argparse.ArgumentParser(description="Compute the loss of a trained tape model over a dataset.")
-    p.add_argument('--DATASET_DIR', type=str, required=True)
-    p.add_argument('--SUBSET', type=str, default="test")
-    p.add_argument('--WEIGHTS', type=str, required=True)
+def none_or_int(argument):
+    """ Parse NoneType or int input arguments from CLI (code/test-model.py:38-42) """
+    if argument == 'None':
+        return None
+    return int(argument)
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Evaluate a trained tape model over a dataset (code/test-model.py).")
+    # GLOBAL (code/test-model.py:48-50)
+    p.add_argument('--DESCRIPTIVE_NAME', type=str, default=None)
+    p.add_argument('--SAVE_FIG', action='store_true', default=False)
+    p.add_argument('--SAVE_AUDIO', action='store_true', default=False)
+    # MODEL (:53-61).  The reference's default is a bare str, which `for weight in WEIGHTS` would walk character by
+    # character; a one-element list here.  It lacks the -L[...] field, so parse_loss raises on it as upstream would.
+    p.add_argument('--MODEL', type=str, default="GRU")
+    p.add_argument('--WEIGHTS', nargs='+', default=["GRU-HS[64]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE]"])
+    p.add_argument('--ADD_DELAY', action='store_true', default=False)
+    p.add_argument('--DELAY_TYPE', type=str, default="Real")
+    p.add_argument('--ADD_NOISE', action='store_true', default=False)
+    p.add_argument('--NOISE_TYPE', type=str, default="Real")
+    # DATASET (:64-77)
+    p.add_argument('--DATASET', type=str, default="ReelToReel_Dataset_MiniPulse100_CHOWTAPE")
+    p.add_argument('--SUBSET', type=str, default="Val")
+    p.add_argument('--FRACTION', type=float, default=1.0)
     p.add_argument('--SEGMENT_LENGTH', type=int, default=None)
+    p.add_argument('--NO_SHUFFLE', action='store_true', default=False)
+    p.add_argument('--DEMODULATE', action='store_true', default=False)
+    p.add_argument('--IDX', type=none_or_int, default=None)
     p.add_argument('--SYNC', type=float, default=0.0)
+    p.add_argument('--COMPUTE_LOSS', action='store_true', default=False)
+    p.add_argument('--DATASET_NOISE', type=str, default="Silence_AKAI_IPS[7.5]_MAXELL")
+    # VISUALIZATIONS (:80-84)
+    p.add_argument('--PLOT_SWEEP', action='store_true', default=False)
+    p.add_argument('--PLOT_TRANSFER', action='store_true', default=False)
+    p.add_argument('--PLOT_PHASE', action='store_true', default=False)
+    p.add_argument('--PLOT_DELAY', action='store_true', default=False)
+    p.add_argument('--ZOOM', type=float, default=None)
+    # this build
+    p.add_argument('--DATASET_DIR', type=str, default=None, help="the dataset directory itself (overrides AUDIO_PATH/DATASET)")
+    p.add_argument('--AUDIO_PATH', type=str, default="../audio/")
+    p.add_argument('--MODEL_PATH', type=str, default="../weights/")
+    p.add_argument('--RESULTS_PATH', type=str, default="../results/")
+    p.add_argument('--TEMP_PATH', type=str, default=".temp/", help="where the loss results are cached (code/test-model.py:304-320)")
     p.add_argument('--BATCH_SIZE', type=int, default=4096, help="segments per launch (the matrix-pipe kernel wants thousands)")
     p.add_argument('--STREAM_CHUNK', type=int, default=8192, help="time chunk of the host->device pipeline; 0 = whole-batch copies")
     p.add_argument('--MAX_DELAY', type=float, default=0.0, help="seconds (DelayAnalyzer.max_delay of the dataset)")
-    p.add_argument('--COMPUTE_LOSS', action='store_true', default=False)
-    p.add_argument('--DEMODULATE', action='store_true', default=False)
-    p.add_argument('--ADD_DELAY', action='store_true', default=False,
-                   help="GRU only: apply the measured delay trajectory to the model output (code/test-model.py:236-240,355-364)")
     p.add_argument('--INIT_LEN', type=int, default=None,
                    help="samples cut from the head of every segment before the losses; default: the reference's "
                         "nextpow2(int(max_delay * fs)) (code/test-model.py:323-324), i.e. 2 for a dataset without delay")
     p.add_argument('--KERNEL', type=str, default="auto")
-    a = p.parse_args(argv)
+    p.add_argument('--SEED', type=int, default=None, help="seed of the shuffled draw / the random example (upstream: unseeded)")
+    p.add_argument('--NO_EXAMPLE', action='store_true', default=False, help="skip the example prediction after the loss")
+    return p
 
+
+def parse_args(argv=None):
+    """Parse + the reference's own argument checks (code/test-model.py:91-99)."""
+    a = build_parser().parse_args(argv)
+    if isinstance(a.WEIGHTS, str):
+        a.WEIGHTS = [a.WEIGHTS]
+    assert not (a.PLOT_SWEEP and a.PLOT_TRANSFER and a.PLOT_DELAY), "Choose either PLOT_SWEEP, PLOT_TRANSFER or PLOT_DELAY"
+    assert a.DELAY_TYPE.lower() in ["real", "generated", "true"], "Choose 'Real', 'Generated' or 'True' as DELAY_TYPE"
+    assert a.NOISE_TYPE.lower() in ["real", "generated"], "Choose 'Real' or 'Generated' as NOISE_TYPE"
+    return a
+
+
+def dataset_path(a):
+    """code/test-model.py:147: os.path.join(AUDIO_PATH, DATASET)."""
+    return a.DATASET_DIR if a.DATASET_DIR else os.path.join(a.AUDIO_PATH, a.DATASET)
+
+
+def dataset_name(a):
+    return os.path.basename(os.path.normpath(a.DATASET_DIR)) if a.DATASET_DIR else a.DATASET
+
+
+def resolve_weights(weight, model_path):
+    """-> (weights-directory name, state_dict or None = take the exported checkpoint of that name)."""
+    for cand in (os.path.join(model_path, weight), weight):
+        best = os.path.join(cand, "best.pth")
+        if os.path.isfile(best):
+            return os.path.basename(os.path.normpath(cand)), torch.load(best, map_location="cpu")   # code/test-model.py:233
+    name = os.path.basename(os.path.normpath(weight))
+    if name not in ntm_amd.weights.available():
+        parse_loss(name)              # a malformed name fails here the way it does upstream (:204)
+        raise SystemExit(f"no best.pth under '{os.path.join(model_path, weight)}' and '{name}' is not an exported checkpoint")
+    return name, None
+
+
+def check_model_flag(model_flag, weights):
+    """The loss loop dispatches on the `--MODEL` string and runs the LAST entry of `--WEIGHTS` (code/test-model.py:345-353);
+    upstream a mismatch ends in a TypeError inside predict().  Here it is an error up front."""
+    last = parse_model(os.path.basename(os.path.normpath(weights[-1])))
+    if model_flag != last:
+        raise SystemExit(f"--MODEL {model_flag} does not match the model type '{last}' of --WEIGHTS {weights[-1]}")
+
+
+def write_wav16(path, x, fs):
+    """`sf.write(path, x, fs)` of code/test-model.py:884-893: libsndfile's default for .wav is 16-bit PCM."""
+    from scipy.io import wavfile
+    x = np.asarray(x, np.float32).reshape(-1)
+    wavfile.write(path, int(fs), np.clip(np.rint(x * 32767.0), -32768, 32767).astype(np.int16))
+
+
+def main(argv=None):
+    a = parse_args(argv)
     rank, world, local = D.init_from_env()
+    say = print if rank == 0 else (lambda *x, **k: None)
+    say("\nArguments:")
+    say(a)
+    ignored = [f"--{k}" for k in OUT_OF_SCOPE if getattr(a, k)]
+    if a.DELAY_TYPE.lower() == "generated":
+        raise SystemExit("--DELAY_TYPE Generated needs the diffusion trajectory generator (code/model.py DiffusionGenerator): out of scope")
+    if ignored:
+        say("out of scope, ignored: " + " ".join(ignored) + "  (figures / noise: see INTEGRATION.md)")
+    check_model_flag(a.MODEL, a.WEIGHTS)
     torch.cuda.set_device(local)
-    feeder = SegmentFeeder(a.DATASET_DIR, subset=a.SUBSET, length=a.SEGMENT_LENGTH, sync=a.SYNC, demodulate=a.DEMODULATE)
-    if a.MAX_DELAY <= 0 and feeder.max_delay > 0:          # dataset.delay_analyzer.max_delay (code/test-model.py:323-324)
+    if a.SEED is not None:
+        np.random.seed(a.SEED)
+
+    # ---- dataset (code/test-model.py:145-154,178-179)
+    say("Dataset (audio)")
+    feeder = SegmentFeeder(dataset_path(a), subset=a.SUBSET, length=a.SEGMENT_LENGTH, sync=a.SYNC, demodulate=a.DEMODULATE,
+                           fraction=a.FRACTION, shuffle=not a.NO_SHUFFLE, seed=a.SEED)
+    fs = feeder.fs
+    if a.MAX_DELAY <= 0 and feeder.max_delay > 0:          # dataset.delay_analyzer.max_delay (code/test-model.py:223,323-324)
         a.MAX_DELAY = feeder.max_delay
-    sd = None
-    if os.path.isdir(a.WEIGHTS):
-        sd = torch.load(os.path.join(a.WEIGHTS, "best.pth"), map_location="cpu")
-    name = os.path.basename(os.path.normpath(a.WEIGHTS))
-    model = ntm_amd.harness.build_model(name, max_delay_seconds=a.MAX_DELAY, fs=feeder.fs, state_dict=sd)
-    model.kernel_variant = a.KERNEL
+
+    # ---- models (code/test-model.py:192-247)
+    models = []
+    for weight in a.WEIGHTS:
+        name, sd = resolve_weights(weight, a.MODEL_PATH)
+        model_type, training_loss = parse_model(name), parse_loss(name)
+        model = ntm_amd.harness.build_model(name, max_delay_seconds=a.MAX_DELAY, fs=fs, state_dict=sd)
+        model.kernel_variant = a.KERNEL
+        md = {"weight": name, "model_type": model_type,
+              "model_id": MODEL_IDS.get(f"{model_type}-{training_loss}", f"{model_type}-{training_loss}"), "model": model}
+        if a.ADD_DELAY:
+            md["delay"] = ntm_amd.TimeVaryingDelayLine(max_delay=int(1.25 * feeder.max_delay * fs))     # :236-240
+        say("=" * 25)
+        for key, value in md.items():
+            say(f"{key.ljust(9)}: {value if key != 'model' else type(value).__name__ + f'(hidden_size={parse_hidden_size(name)})'}")
+        say("=" * 25, "\n")
+        models.append(md)
+    model, name = models[-1]["model"], models[-1]["weight"]          # what the loss loop sees upstream (:345-353)
+    delay = models[-1].get("delay")
     is_dd = isinstance(model, ntm_amd.DiffDelRNN)
     # code/test-model.py:323-324: INIT_LEN = nextpow2(int(max_delay * fs)) -- for max_delay == 0 that is 2 (the
     # reference's own "# 2**10" comment there is wrong: nextpow2(0) == 2)
-    init_len = a.INIT_LEN if a.INIT_LEN is not None else ntm_amd.harness.init_len(a.MAX_DELAY, feeder.fs)
-    if not a.COMPUTE_LOSS:
-        print(f"{len(feeder)} segments of {feeder.length} samples @ {feeder.fs} Hz; nothing to do without --COMPUTE_LOSS")
-        return {}
-    per = {"ESR": [], "DCPreESR": [], "MultiSTFT": []}
-    mrstft = ntm_amd.MRSTFTLoss()
-    with_stft = feeder.length - init_len > 1024               # the largest STFT frame needs > 1024 samples
-    def batches():
-        if a.DEMODULATE or a.ADD_DELAY or a.STREAM_CHUNK <= 0:
-            for xin, tgt, dt, _ in feeder.batches(a.BATCH_SIZE, "cuda", rank, world):
-                if is_dd:
-                    assert dt is not None, "DiffDelGRU needs trajectory_<id>_*.npy side-cars"
-                    out, _ = model.predict(xin, dt * feeder.fs)
-                else:
-                    out = model.predict(xin)
-                yield xin, tgt, out, dt
-        else:
-            # predict straight from the feeder's pinned files, H2D copies pipelined along time under the launches
-            lo, hi = D.shard_range(len(feeder), rank, world)
-            for b0 in range(lo, hi, a.BATCH_SIZE):
-                out, xin, tgt = feeder.predict_streamed(model, b0, min(hi, b0 + a.BATCH_SIZE), chunk=a.STREAM_CHUNK)
-                yield xin, tgt, out, None
+    init_len = a.INIT_LEN if a.INIT_LEN is not None else ntm_amd.harness.init_len(a.MAX_DELAY, fs)
 
-    delay = None
-    if a.ADD_DELAY and not is_dd:
-        assert feeder.max_delay > 0, "--ADD_DELAY needs delay trajectories (stereo dataset or side-cars)"
-        delay = ntm_amd.TimeVaryingDelayLine(max_delay=int(1.25 * feeder.max_delay * feeder.fs))      # code/test-model.py:237-238
-    for xin, tgt, out, dt in batches():
-        if delay is not None:
-            out = ntm_amd.harness.apply_delay(delay, dt * feeder.fs, out)
-        n = xin.shape[-1] - init_len
-        for key, fn in (("ESR", esr_sums), ("DCPreESR", esr_dcpre_sums)):
-            s = fn(out, tgt, skip=init_len)
-            per[key].append((s[:, 0] / n) / (s[:, 1] / n + ESR_EPS))
-        if with_stft:
-            per["MultiSTFT"].append(mrstft.per_segment(out, tgt, skip=init_len))
-    # every rank issues the SAME collectives whatever its shard holds (a rank with no segments -- more ranks than
-    # segments -- reduces empty tensors): the key set depends on the global segment length only
-    if not with_stft:
-        del per["MultiSTFT"]
-    res = {k: D.reduce_loss_sums(torch.cat(v) if v else torch.zeros(0, device="cuda", dtype=torch.float64))
-           for k, v in per.items()}
-    if rank == 0:
-        print("\n===== Stats: =====")
-        print(f"Model:      {name}\nDataset:    {os.path.basename(os.path.normpath(a.DATASET_DIR))}\nSubset:     {a.SUBSET}")
-        print(f"Segments:   {res['ESR']['segments']}\n")
-        for k, v in res.items():
-            print(f"{k.ljust(9)}: {v['mean_segment_loss']:.6f}")
-        print("\n==================")
-    return {k: v["mean_segment_loss"] for k, v in res.items()}
+    results = {}
+    if a.COMPUTE_LOSS:
+        results = compute_loss(a, feeder, model, name, delay, is_dd, init_len, rank, world, say)
+    else:
+        say(f"{len(feeder)} segments of {feeder.length} samples @ {fs} Hz; no loss without --COMPUTE_LOSS")
+    if rank == 0 and not a.NO_EXAMPLE:
+        example_prediction(a, feeder, models, init_len, say)
+    return results
+
+
+def compute_loss(a, feeder, model, name, delay, is_dd, init_len, rank, world, say):
+    """code/test-model.py:296-418: per-segment losses, mean over segments, cached under TEMP_PATH as upstream."""
+    fs = feeder.fs
+    say("\nComputing loss over dataset ...", end="")
+    save_path = os.path.join(a.TEMP_PATH, 'loss', f"{dataset_name(a)}", f"{feeder.subset}")
+    save_name = f"{a.WEIGHTS}_DELAY[{a.ADD_DELAY}]_DEMODULATE[{a.DEMODULATE}]_NOISE[{a.ADD_NOISE}].npy"
+    cached = os.path.join(save_path, save_name)
+    if os.path.exists(cached):
+        say(" Loading pre-computed!")
+        results = np.load(cached, allow_pickle=True).item()
+        n_seg = len(feeder)
+    else:
+        say(" Starting analysis...")
+        per = {"ESR": [], "DCPreESR": [], "MultiSTFT": []}
+        mrstft = ntm_amd.MRSTFTLoss()
+        seg_len = feeder.length - (int(feeder.mean_delay * fs) if a.DEMODULATE else 0)    # demodulation trims the tail
+        with_stft = seg_len - init_len > 1024                  # the largest STFT frame needs > 1024 samples
+
+        def batches():
+            if a.DEMODULATE or a.ADD_DELAY or a.STREAM_CHUNK <= 0:
+                for xin, tgt, dt, _ in feeder.batches(a.BATCH_SIZE, "cuda", rank, world):
+                    if is_dd:
+                        assert dt is not None, "DiffDelGRU needs trajectory_<id>_*.npy side-cars"
+                        out, _ = model.predict(xin, dt * fs)
+                    else:
+                        out = model.predict(xin)
+                    yield xin, tgt, out, dt
+            else:
+                # predict straight from the feeder's pinned files, H2D copies pipelined along time under the launches
+                lo, hi = D.shard_range(len(feeder), rank, world)
+                for b0 in range(lo, hi, a.BATCH_SIZE):
+                    out, xin, tgt = feeder.predict_streamed(model, b0, min(hi, b0 + a.BATCH_SIZE), chunk=a.STREAM_CHUNK)
+                    yield xin, tgt, out, None
+
+        if delay is not None and not is_dd:
+            assert feeder.max_delay > 0, "--ADD_DELAY needs delay trajectories (stereo dataset or side-cars)"
+        for xin, tgt, out, dt in batches():
+            if delay is not None and not is_dd:                                   # :355-364 (`ADD_DELAY and MODEL == "GRU"`)
+                out = ntm_amd.harness.apply_delay(delay, dt * fs, out)
+            n = xin.shape[-1] - init_len
+            for key, fn in (("ESR", esr_sums), ("DCPreESR", esr_dcpre_sums)):
+                s = fn(out, tgt, skip=init_len)
+                per[key].append((s[:, 0] / n) / (s[:, 1] / n + ESR_EPS))
+            if with_stft:
+                per["MultiSTFT"].append(mrstft.per_segment(out, tgt, skip=init_len))
+        # every rank issues the SAME collectives whatever its shard holds (a rank with no segments -- more ranks than
+        # segments -- reduces empty tensors): the key set depends on the global segment length only
+        if not with_stft:
+            del per["MultiSTFT"]
+        res = {k: D.reduce_loss_sums(torch.cat(v) if v else torch.zeros(0, device="cuda", dtype=torch.float64))
+               for k, v in per.items()}
+        n_seg = res['ESR']['segments']
+        results = {k: v["mean_segment_loss"] for k, v in res.items()}
+        if rank == 0:
+            os.makedirs(save_path, exist_ok=True)
+            np.save(cached, results)
+    say()
+    say("=" * 5, "Stats:", "=" * 5)
+    say(f"Model:      {a.WEIGHTS}")
+    say(f"Dataset:    {dataset_name(a)}")
+    say(f"Subset:     {a.SUBSET}")
+    say(f"ADD_DELAY:  {a.ADD_DELAY}")
+    say(f"DEMODULATE: {a.DEMODULATE}")
+    say(f"ADD_NOISE:  {a.ADD_NOISE}")
+    say(f"Segments:   {n_seg}\n")
+    for key, value in results.items():
+        say(f"{key.ljust(9)}: {'{:.6f}'.format(value)}")
+    say()
+    say("=" * 18)
+    return results
+
+
+@torch.no_grad()
+def example_prediction(a, feeder, models, init_len, say):
+    """code/test-model.py:420-552 without the figures: every model of `--WEIGHTS` on segment `--IDX` (random when None),
+    the DiffDelGRU with the trajectory `--DELAY_TYPE` selects, `--ADD_DELAY` for GRU models, per-second losses of the
+    example with `--COMPUTE_LOSS` (:528-551), WAV export with `--SAVE_AUDIO` (:876-893)."""
+    fs = feeder.fs
+    say("\nMaking example prediction ...")
+    sample_idx = np.random.randint(0, high=len(feeder)) if a.IDX is None else a.IDX
+    input, target, meta = feeder[sample_idx]
+    input, target = input[None, :1, :].cuda(), target[None, :1, :].cuda()
+    say(f"idx = {sample_idx}")
+    say(f"filename: {meta['target_name']}")
+    d_traj = None
+    if "delay_trajectory" in meta:
+        if a.DELAY_TYPE == "True":
+            src = meta
+        else:                                         # "Real": the trajectory of a random example (:456-464)
+            _, __, src = feeder[np.random.randint(0, high=len(feeder))]
+        d_traj = (torch.as_tensor(src['delay_trajectory']).float().view(1, 1, -1) * fs).cuda()
+    outs = {}
+    for md in models:
+        model = md['model']
+        x_in, tgt = input, target
+        if md['model_type'] == "GRU":
+            output = model.predict(x_in)
+        else:
+            assert d_traj is not None, "DiffDelGRU needs trajectory_<id>_*.npy side-cars"
+            output, output_pre_d = model.predict(x_in, d_traj)
+            x_in, tgt, output = x_in[:, :, init_len:], tgt[:, :, init_len:], output[:, :, init_len:]     # :489-496
+        if a.ADD_DELAY and a.MODEL == "GRU" and md['model_type'] == "GRU":
+            assert d_traj is not None, "--ADD_DELAY needs delay trajectories (stereo dataset or side-cars)"
+            output = ntm_amd.harness.apply_delay(md['delay'], d_traj, output, segment_length=2**12)       # :259-290
+            start_delay = int(d_traj[0, 0, 0])                                                           # :512-521
+            x_in, tgt, output = x_in[:, :, start_delay:], tgt[:, :, start_delay:], output[:, :, start_delay:]
+        outs[md['model_id']] = output
+        if a.COMPUTE_LOSS and output.shape[-1] > 0:
+            SEG = 44100                                                                                  # :530
+            nseg = int(np.ceil(output.shape[-1] / SEG))
+            tot = {"ESR": 0.0, "DCPreESR": 0.0}
+            for k in range(nseg):
+                o, t = output[:, :, k * SEG:(k + 1) * SEG], tgt[:, :, k * SEG:(k + 1) * SEG]
+                tot["ESR"] += float(ntm_amd.model.ESRLoss()(o, t))
+                tot["DCPreESR"] += float(ntm_amd.model.DCPreESR()(o, t))
+            say(f"example loss [{md['model_id']}]: " + ", ".join(f"{k} {v / nseg:.6f}" for k, v in tot.items()))
+        md['example'] = (x_in, tgt, output)
+    if a.SAVE_AUDIO:
+        say("\nSaving audio...")
+        basename = dataset_name(a) + (f"_{a.DESCRIPTIVE_NAME}" if a.DESCRIPTIVE_NAME else "")
+        os.makedirs(a.RESULTS_PATH, exist_ok=True)
+        x_in, tgt, _ = models[-1]['example']
+        write_wav16(os.path.join(a.RESULTS_PATH, f"{basename}_input.wav"), x_in.cpu().numpy(), fs)
+        write_wav16(os.path.join(a.RESULTS_PATH, f"{basename}_target.wav"), tgt.cpu().numpy(), fs)
+        for mid, out in outs.items():
+            write_wav16(os.path.join(a.RESULTS_PATH, f"{basename}_prediction_{mid}.wav"), out.cpu().numpy(), fs)
+    return outs
 
 
 if __name__ == "__main__":
