@@ -164,7 +164,7 @@ hipError_t launch_delay(const float *x, const float *d, float *y, int64_t B, int
 hipError_t launch_delay_update(const float *x, int64_t B, int64_t T, float *dl_state, int D, const int32_t *err_flag,
                                hipStream_t stream)
 {
-    if (B == 0 || T == 0 || D <= 0) return hipSuccess;
+    if (B <= 0 || T <= 0 || D <= 0) return hipSuccess;
     hipLaunchKernelGGL(delay_update_kernel, dim3((unsigned)B), dim3(DU_THREADS), 0, stream, x, dl_state, T, D, err_flag);
     return hipGetLastError();
 }

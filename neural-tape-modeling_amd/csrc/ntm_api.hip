@@ -112,6 +112,9 @@ int ntm_gru_forward_esr(const float *w_ih, const float *w_hh, const float *b_ih,
                         const float *b_o, int H, const float *x, float *y, int64_t B, int64_t T, int64_t x_stride_b,
                         int64_t y_stride_b, float *h_state, const float *target, int64_t skip, double *esr_out, void *stream)
 {
+    // every argument is checked BEFORE anything is enqueued: an NTM_EINVAL leaves y, h_state and esr_out untouched
+    if (H != 8 && H != 16 && H != 32 && H != NTM_HIDDEN)
+        return fail(NTM_EINVAL, "ntm_gru_forward_esr: hidden sizes 8, 16, 32 and 64 are compiled");
     if (B < 0 || T < 0 || skip < 0 || skip > T) return fail(NTM_EINVAL, "ntm_gru_forward_esr: bad size");
     if (B == 0) return NTM_OK;
     if (!target || !esr_out) return fail(NTM_EINVAL, "ntm_gru_forward_esr: null pointer");
@@ -119,17 +122,19 @@ int ntm_gru_forward_esr(const float *w_ih, const float *w_hh, const float *b_ih,
         hipError_t ez = hipMemsetAsync(esr_out, 0, (size_t)B * 2 * sizeof(double), (hipStream_t)stream);
         return ez == hipSuccess ? NTM_OK : hip_fail(ez, "ntm_gru_forward_esr");
     }
+    if (!w_ih || !w_hh || !b_ih || !b_hh || !w_o || !x || !y) return fail(NTM_EINVAL, "ntm_gru_forward_esr: null pointer");
+    if (x_stride_b < T || y_stride_b < T) return fail(NTM_EINVAL, "ntm_gru_forward_esr: stride < T");
     if (target == y) return fail(NTM_EINVAL, "ntm_gru_forward_esr: target must not alias y");
     // streams the matrix-pipe kernel takes (as ntm_gru_forward's NTM_GRU_AUTO decides): there the sums ride in the launch
     int64_t fused = 0;
-    if (H == NTM_HIDDEN && B > NTM_GRU_LAT_MAX_B && T > 0 && (skip & 3) == 0) {
+    if (H == NTM_HIDDEN && B > NTM_GRU_LAT_MAX_B && (skip & 3) == 0) {
         const int64_t round = 16 * (int64_t)ntm::device_cus();
         const int64_t full = (B / round) * round, rem = B - full;
         fused = (full > 0 && rem > 0 && rem <= NTM_GRU_LAT_MAX_B) ? full : B;
     }
+    if (fused < B && y_stride_b != T)
+        return fail(NTM_EINVAL, "ntm_gru_forward_esr: the streaming ESR pass (streams outside the matrix-pipe launch) needs contiguous y rows (stride T)");
     if (fused > 0) {
-        if (!w_ih || !w_hh || !b_ih || !b_hh || !w_o || !x || !y) return fail(NTM_EINVAL, "ntm_gru_forward_esr: null pointer");
-        if (x_stride_b < T || y_stride_b < T) return fail(NTM_EINVAL, "ntm_gru_forward_esr: stride < T");
         ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, fused, T, x_stride_b, y_stride_b, nullptr, 0, 0};
         a.tgt = target;
         a.esr_out = esr_out;
@@ -142,7 +147,6 @@ int ntm_gru_forward_esr(const float *w_ih, const float *w_hh, const float *b_ih,
         int rc = ntm_gru_forward(w_ih, w_hh, b_ih, b_hh, w_o, b_o, H, x + fused * x_stride_b, y + fused * y_stride_b, r, T,
                                  x_stride_b, y_stride_b, h_state ? h_state + fused * H : nullptr, stream);
         if (rc != NTM_OK) return rc;
-        if (y_stride_b != T) return fail(NTM_EINVAL, "ntm_gru_forward_esr: the streaming ESR pass needs contiguous y rows (stride T)");
         hipError_t e = ntm::launch_esr(y + fused * T, target + fused * T, r, T, skip, 1, esr_out + 2 * fused, (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "ntm_gru_forward_esr");
     }
@@ -176,7 +180,9 @@ static int diffdel_impl(const float *w_ih, const float *w_hh, const float *b_ih,
     // target != NULL: also the per-stream ESR sums of y against target over [skip, T) (ntm_diffdel_gru_forward_esr): inside the
     // fused launch where it runs and skip is a multiple of 4, by the streaming pass (one row per stream) everywhere else
     const bool esr_in_kernel = target && (skip & 3) == 0 && !warmup;
-    if (target && B > 0 && T == 0) {            // no samples: the sums are zero
+    if (B < 0 || T < 0 || D < 0) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: negative size");
+    if (B == 0) return NTM_OK;
+    if (target && T == 0) {            // no samples: the sums are zero
         hipError_t ez = hipMemsetAsync(esr_out, 0, (size_t)B * 2 * sizeof(double), (hipStream_t)stream);
         if (ez != hipSuccess) return hip_fail(ez, "ntm_diffdel_gru_forward_esr");
     }
@@ -198,8 +204,11 @@ static int diffdel_impl(const float *w_ih, const float *w_hh, const float *b_ih,
         const int64_t full = (B / round) * round, rem = B - full;
         fused = (full > 0 && rem > 0 && rem <= NTM_GRU_LAT_MAX_B) ? full : B;
     }
+    // A warm-up call (code/model.py:288-292: the delay line only moves its buffer on, y = pre_d) takes the two-pass form in
+    // every mode: the fused kernel's delay stage is idle then and reads no delays, while the reference evaluates its range
+    // assert BEFORE the warm-up branch (code/model.py:284 vs :288) -- delay_apply_kernel does, in warm-up too.
+    if (warmup) fused = 0;
     if (fused > 0) {
-        if (B < 0 || T < 0 || D < 0) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: negative size");
         if (T == 0) return NTM_OK;
         if (!w_ih || !w_hh || !b_ih || !b_hh || !w_o || !x || !d || !y || (D > 0 && !dl_state))
             return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: null pointer");

@@ -132,18 +132,23 @@ def test_g19_every_shipped_checkpoint(ntm, name):
                 outs[mode] = (yb[0], pb[0])
                 row[f"{tag}_{mode}_y"], _, _ = bar(yb[0], ref_y, y64, f"{tag} predict B={TILE_B} {mode} y")
                 row[f"{tag}_{mode}_pre"], _, _ = bar(pb[0], ref_p, p64, f"{tag} predict B={TILE_B} {mode} pre_d")
-            assert np.array_equal(outs["fused"][0], outs["two_pass"][0]) and np.array_equal(outs["fused"][1], outs["two_pass"][1])
-            # teacher-forced from the reference's warm state (hidden + the 1024 samples the warm-up left in the buffer)
-            if tag == "toy":
-                m.delay_mode = "auto"
-                for B in (1, TILE_B):
-                    m.initialize_hidden(B, m.max_delay)
-                    m.hidden = dev(np.broadcast_to(g[k + "_hwarm"], (1, B, 64)).copy())
-                    m.diffdel.buffer[:, 0, -1024:] = dev(g[k + "_bwarm"])
-                    yt, pt = m(tile(xl[:Tc], B), tile(d, B))
-                    e = max(float(np.abs(yt.cpu().numpy()[0, 0] - ref_y).max()), float(np.abs(pt.cpu().numpy()[0, 0] - ref_p).max()))
-                    row[f"forced_B{B}"] = e
-                    assert e < TOL, row
+            # teacher-forced from the reference's warm state (hidden + the 1024 samples the warm-up left in the buffer; the
+            # same for both delay lengths): 1e-5 for every checkpoint, and from the SAME state the fused step and the two-pass
+            # step give the same bits (their predict()s differ in the last place only because a forced mode also picks the
+            # GRU kernel of the B = 1 warm-up)
+            forced = {}
+            for mode, B in (("auto", 1), ("fused", TILE_B), ("two_pass", TILE_B)):
+                m.delay_mode = mode
+                m.initialize_hidden(B, m.max_delay)
+                m.hidden = dev(np.broadcast_to(g[k + "_hwarm"], (1, B, 64)).copy())
+                m.diffdel.buffer[:, 0, -1024:] = dev(g[k + "_bwarm"])
+                yt, pt = m(tile(xl[:Tc], B), tile(d, B))
+                forced[mode] = (yt.cpu().numpy()[ROWS if B > 1 else [0], 0], pt.cpu().numpy()[ROWS if B > 1 else [0], 0], m.diffdel.buffer.cpu().numpy()[0, 0])
+                e = max(float(np.abs(forced[mode][0][0] - ref_y).max()), float(np.abs(forced[mode][1][0] - ref_p).max()))
+                row[f"{tag}_forced_{mode}_B{B}"] = e
+                assert e < TOL, row
+            for a, b in zip(forced["fused"], forced["two_pass"]):
+                assert np.array_equal(a, b)
     record(**row)
 
 
@@ -214,6 +219,53 @@ def test_g20_diffdel_long_and_real_tape_delay(ntm, tag):
         row[f"{mode}_y"], _, _ = bar(yb[0], ref_y, y64, f"B={TILE_B} {mode} y")
         row[f"{mode}_pre"], _, _ = bar(pb[0], ref_p, p64, f"B={TILE_B} {mode} pre_d")
         assert np.abs(buf[0] - g[f"dd_{tag}_buffer"]).max() < TOL
-    for a, b in zip(outs["fused"], outs["two_pass"]):
-        assert np.array_equal(a, b)
+    # from the SAME warm state the two forms of the step give the same bits (outputs, hidden state, delay buffer)
+    m.delay_mode = "two_pass"
+    m.initialize_hidden(1, m.max_delay)
+    m.warm_start()
+    h0, b0 = m.hidden.clone(), m.diffdel.buffer.clone()
+    same = {}
+    for mode in ("fused", "two_pass"):
+        m.delay_mode = mode
+        m.initialize_hidden(TILE_B, m.max_delay)
+        m.hidden = h0.expand(1, TILE_B, 64).contiguous()
+        m.diffdel.buffer = b0.expand(TILE_B, 1, -1).contiguous()
+        yb, pb = m(tile(x), tile(d))
+        same[mode] = (yb[ROWS].cpu(), pb[ROWS].cpu(), m.hidden[:, ROWS].cpu(), m.diffdel.buffer[ROWS].cpu())
+    for a, b in zip(same["fused"], same["two_pass"]):
+        assert torch.equal(a, b)
     record(**row)
+
+
+W_D = "DiffDelGRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE_WOWFLUTTER]_BEST"
+
+
+@pytest.mark.parametrize("bad", [302.5, float("nan")])
+def test_warmup_call_checks_the_delay_range_in_every_mode(ntm, bad):
+    """code/model.py:284 asserts max_delay >= max(dt) BEFORE the warm-up branch (:288).  Round 3's fused launch skipped the
+    check in warm-up mode (it reads no delays there); warm-up calls now take the two-pass form in every mode.  A violating
+    (or NaN) trajectory raises and leaves hidden-state-independent state -- the delay buffer -- untouched; a legal warm-up
+    gives the same bits in all three modes: y == pre_d, buffer = the last D samples."""
+    rng = np.random.default_rng(3)
+    B, T = TILE_B, 512
+    x = dev(rng.uniform(-0.5, 0.5, (B, 1, T)).astype(np.float32))
+    d_ok = dev(np.full((B, 1, T), 100.25, np.float32))
+    d_bad = d_ok.clone()
+    d_bad[7, 0, 33] = bad
+    outs = []
+    for mode in ("auto", "fused", "two_pass"):
+        m = build(ntm, W_D, 300)
+        m.delay_mode = mode
+        m.initialize_hidden(B, m.max_delay)
+        buf0 = m.diffdel.buffer.clone()
+        with pytest.raises(AssertionError):
+            m(x, d_bad, warmup=True)
+        assert torch.equal(m.diffdel.buffer, buf0)
+        m.initialize_hidden(B, m.max_delay)
+        y, pre = m(x, d_ok, warmup=True)
+        assert torch.equal(y, pre) and torch.equal(m.diffdel.buffer[:, 0], pre[:, 0, -301:])
+        y2, pre2 = m(x, d_ok)                       # and the step after the warm-up reads that buffer
+        outs.append((pre.cpu(), y2.cpu(), pre2.cpu(), m.diffdel.buffer.cpu()))
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            assert torch.equal(a, b)

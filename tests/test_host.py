@@ -51,6 +51,20 @@ def test_cabi_pure_host_entry_points():
                                 ntm_amd._lib.NTM_GRU_MFMA2, None) == -1
     assert b"hidden size 64 only" in L.ntm_last_error()
     assert L.ntm_esr_sums(None, None, 1, 10, 11, 1, None, None) == -1
+    two = ctypes.c_void_p(32)
+    # ntm_gru_forward_esr rejects a strided y for streams outside the matrix-pipe launch BEFORE anything is enqueued
+    # (round 3 launched the forward first and then returned NTM_EINVAL with y half-written)
+    assert L.ntm_gru_forward_esr(one, one, one, one, one, None, 64, one, one, 4, 100, 100, 128, None, two, 0, one, None) == -1
+    assert b"contiguous y rows" in L.ntm_last_error()
+    assert L.ntm_gru_forward_esr(one, one, one, one, one, None, 24, one, one, 4, 100, 100, 100, None, two, 0, one, None) == -1
+    assert L.ntm_gru_forward_esr(one, one, one, one, one, None, 64, one, None, 4, 100, 100, 100, None, two, 0, one, None) == -1
+    assert b"null pointer" in L.ntm_last_error()
+    # the DiffDelGRU entries check signs first (a negative B used to reach a launch with (unsigned)B blocks), B == 0 is a no-op
+    for mode in (ntm_amd._lib.DIFFDEL_MODES["auto"], ntm_amd._lib.DIFFDEL_MODES["two_pass"]):
+        assert L.ntm_diffdel_gru_forward_ex(one, one, one, one, one, 64, one, one, one, ctypes.c_void_p(32), -1, 10, None, one, 5, 0, None, mode, None) == -1
+        assert b"negative size" in L.ntm_last_error()
+        assert L.ntm_diffdel_gru_forward_ex(one, one, one, one, one, 64, one, one, one, ctypes.c_void_p(32), 0, 10, None, one, 5, 0, None, mode, None) == 0
+    assert L.ntm_diffdel_gru_forward_ex(one, one, one, one, one, 64, one, one, one, ctypes.c_void_p(32), 3, 10, None, one, -5, 0, None, 0, None) == -1
     assert L.ntm_esr_splits(4096, 65536, 1024) == 1 and L.ntm_esr_splits(1, 65536, 0) == 16 and L.ntm_esr_splits(16, 8192, 0) == 2
 
 
