@@ -32,7 +32,7 @@ extern "C" {
 #define NTM_EHIP (-2)    /* HIP runtime error (launch failed, no device)               */
 #define NTM_EDELAY (-3)  /* reserved for host-side delay-range checks                  */
 
-#define NTM_ABI_VERSION 5 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag.  3: the TCN scratch is padded (ntm_tcn_scratch_floats grew), dilation / length limits.  4: ntm_diffdel_gru_forward is ONE fused launch where the matrix-pipe kernel runs (+ ntm_diffdel_gru_forward_ex).  5: ntm_gru_forward_esr, ntm_diffdel_gru_forward_esr */
+#define NTM_ABI_VERSION 6 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag.  3: the TCN scratch is padded (ntm_tcn_scratch_floats grew), dilation / length limits.  4: ntm_diffdel_gru_forward is ONE fused launch where the matrix-pipe kernel runs (+ ntm_diffdel_gru_forward_ex).  5: ntm_gru_forward_esr, ntm_diffdel_gru_forward_esr.  6: ntm_tcn_forward works through the batch in stream chunks, ntm_tcn_scratch_floats is bounded (<= 2.0e9 floats + padding for any B), ntm_tcn_chunk_streams; DiffDelGRU warm-up calls always take the two-pass form */
 
 #define NTM_HIDDEN 64 /* hidden size of every shipped checkpoint (HS[64]): matrix-pipe and low-latency kernels.
                          H = 8, 16, 32 (the reference's constructor default is 8, code/model.py:22; its training
@@ -277,11 +277,15 @@ int ntm_fir_f64(const double *x, double *y, int64_t B, int64_t N, const double *
  * then a 1x1 conv to one channel.  params (device), block after block:
  *   W[C_in][K][C], b[C], alpha[C], R[C_in][C]   (C_in = 1 for block 0, C afterwards), then out_w[C], out_b[1].  x,y [B,T] contiguous; dil[L] host array; `scratch`
  * holds ntm_tcn_scratch_floats(B,T,C) floats (two activation buffers, each padded by one 16-row block: always ask this
- * function).  Limits: T < 2^31 - 2^25, 1 <= dil[l] <= 2^20 (NTM_EINVAL otherwise).
+ * function).  The batch is worked through in chunks of ntm_tcn_chunk_streams(B,T,C) streams -- streams are independent, the
+ * chunks' launches follow each other on `stream` and reuse the same two buffers -- so that one activation buffer never exceeds
+ * 1e9 floats (4 GB) whatever B is: 2 x 4 GB for 32 768 x 65 536 instead of 2 x 275 GB; same results bit for bit as one
+ * launch set.  Limits: T < 2^31 - 2^25, 1 <= dil[l] <= 2^20 (NTM_EINVAL otherwise).
  */
 int ntm_tcn_forward(const float *params, int L, int C, int K, const int *dil, const float *x,
                     float *y, int64_t B, int64_t T, float *scratch, void *stream);
 int64_t ntm_tcn_scratch_floats(int64_t B, int64_t T, int C);
+int64_t ntm_tcn_chunk_streams(int64_t B, int64_t T, int C);
 
 #ifdef __cplusplus
 }

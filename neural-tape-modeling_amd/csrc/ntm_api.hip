@@ -424,10 +424,30 @@ int ntm_fir_f64(const double *x, double *y, int64_t B, int64_t N, const double *
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_fir_f64");
 }
 
+// The batch is processed in chunks of streams (streams are independent, the launches of a chunk follow each other on the
+// caller's stream and reuse the same two activation buffers): the scratch is bounded by TCN_SCRATCH_BUDGET floats per
+// activation buffer whatever B is -- 4096 x 65 536 x 32 ch took two 34.4 GB buffers as one launch set, and the per-GPU
+// shapes of BASELINE configs[4] (B >= 8192) did not fit at all.  Chunks are equal-sized (the last may be smaller).
+static const int64_t TCN_SCRATCH_BUDGET = 1000000000;      // floats per activation buffer (4 GB); two buffers
+static int64_t tcn_chunk_streams(int64_t B, int64_t T, int C)
+{
+    int64_t most = TCN_SCRATCH_BUDGET / (T * (int64_t)C);
+    if (most < 1) most = 1;                                // one stream longer than the budget: that stream alone
+    if (B <= most) return B;
+    const int64_t chunks = (B + most - 1) / most;
+    return (B + chunks - 1) / chunks;
+}
+
 int64_t ntm_tcn_scratch_floats(int64_t B, int64_t T, int C)
 {
     if (B <= 0 || T <= 0 || C <= 0) return 0;
-    return 2 * (B * T * (int64_t)C + 16 * (int64_t)C);      // two activation buffers, each padded by one 16-row block
+    return 2 * (tcn_chunk_streams(B, T, C) * T * (int64_t)C + 16 * (int64_t)C);      // two activation buffers, each padded by one 16-row block
+}
+
+int64_t ntm_tcn_chunk_streams(int64_t B, int64_t T, int C)
+{
+    if (B <= 0 || T <= 0 || C <= 0) return 0;
+    return tcn_chunk_streams(B, T, C);
 }
 
 int ntm_tcn_forward(const float *params, int L, int C, int K, const int *dil, const float *x, float *y, int64_t B,
@@ -442,8 +462,13 @@ int ntm_tcn_forward(const float *params, int L, int C, int K, const int *dil, co
     if (T >= ((int64_t)1 << 31) - (1 << 25)) return fail(NTM_EINVAL, "ntm_tcn_forward: T must be below 2^31 - 2^25 samples");
     for (int l = 0; l < L; ++l)
         if (dil[l] <= 0 || dil[l] > (1 << 20)) return fail(NTM_EINVAL, "ntm_tcn_forward: dilations must lie in [1, 2^20]");
-    hipError_t e = ntm::launch_tcn(params, L, C, K, dil, x, y, B, T, scratch, (hipStream_t)stream);
-    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_tcn_forward");
+    const int64_t bc = tcn_chunk_streams(B, T, C);
+    for (int64_t b0 = 0; b0 < B; b0 += bc) {
+        const int64_t n = B - b0 < bc ? B - b0 : bc;
+        hipError_t e = ntm::launch_tcn(params, L, C, K, dil, x + b0 * T, y + b0 * T, n, T, scratch, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "ntm_tcn_forward");
+    }
+    return NTM_OK;
 }
 
 }  // extern "C"

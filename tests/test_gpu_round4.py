@@ -269,3 +269,20 @@ def test_warmup_call_checks_the_delay_range_in_every_mode(ntm, bad):
     for o in outs[1:]:
         for a, b in zip(o, outs[0]):
             assert torch.equal(a, b)
+
+
+def test_tcn_stream_chunks_bit_identical_and_bounded(ntm):
+    """ntm_tcn_forward works through the batch in stream chunks (<= 1e9 floats per activation buffer): 6 streams of 2^23
+    samples = 2 chunks of 3; same bits as each stream alone (one chunk each), scratch as ntm_tcn_scratch_floats says."""
+    L = ntm._lib.lib()
+    B, T = 6, 1 << 23
+    assert L.ntm_tcn_chunk_streams(B, T, 32) == 3
+    tcn = ntm.TCN().to("cuda")
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.rand(B, 1, T, generator=g, device="cuda") - 0.5
+    y = tcn(x)
+    assert tcn._scratch.numel() == L.ntm_tcn_scratch_floats(B, T, 32) == 2 * (3 * T * 32 + 512)
+    for b in (0, 2, 3, 5):
+        assert torch.equal(tcn(x[b:b + 1]), y[b:b + 1])
+    # and the bench's shape: 4096 x 65536 needs 2 x 3.8 GB now (9 chunks of 456 streams), 32768 x 65536 the same
+    assert L.ntm_tcn_scratch_floats(32768, 65536, 32) == L.ntm_tcn_scratch_floats(4096, 65536, 32) <= 2 * 10**9 + 1024
