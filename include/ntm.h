@@ -277,10 +277,13 @@ int ntm_fir_f64(const double *x, double *y, int64_t B, int64_t N, const double *
  * then a 1x1 conv to one channel.  params (device), block after block:
  *   W[C_in][K][C], b[C], alpha[C], R[C_in][C]   (C_in = 1 for block 0, C afterwards), then out_w[C], out_b[1].  x,y [B,T] contiguous; dil[L] host array; `scratch`
  * holds ntm_tcn_scratch_floats(B,T,C) floats (two activation buffers, each padded by one 16-row block: always ask this
- * function).  The batch is worked through in chunks of ntm_tcn_chunk_streams(B,T,C) streams -- streams are independent, the
- * chunks' launches follow each other on `stream` and reuse the same two buffers -- so that one activation buffer never exceeds
- * 1e9 floats (4 GB) whatever B is: 2 x 4 GB for 32 768 x 65 536 instead of 2 x 275 GB; same results bit for bit as one
- * launch set.  Limits: T < 2^31 - 2^25, 1 <= dil[l] <= 2^20 (NTM_EINVAL otherwise).
+ * function).  A batch whose activations exceed 8 GB is worked through in chunks of ntm_tcn_chunk_streams(B,T,C) streams
+ * (streams are independent; same results bit for bit): the scratch never exceeds 2e9 floats (+ padding) whatever B is --
+ * 8 GB for 32 768 x 65 536 instead of 2 x 275 GB.  Chunks alternate between two lanes, each with its own pair of
+ * activation buffers inside `scratch` and its own HIP stream, forked from and joined to `stream` by events (created and
+ * destroyed inside the call): the call is ordered on `stream` like any other, nothing outlives it, and one chunk's drain
+ * and HBM-bound first block run under the other chunk's matrix-pipe blocks.  Limits: T < 2^31 - 2^25,
+ * 1 <= dil[l] <= 2^20 (NTM_EINVAL otherwise).
  */
 int ntm_tcn_forward(const float *params, int L, int C, int K, const int *dil, const float *x,
                     float *y, int64_t B, int64_t T, float *scratch, void *stream);

@@ -424,30 +424,36 @@ int ntm_fir_f64(const double *x, double *y, int64_t B, int64_t N, const double *
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_fir_f64");
 }
 
-// The batch is processed in chunks of streams (streams are independent, the launches of a chunk follow each other on the
-// caller's stream and reuse the same two activation buffers): the scratch is bounded by TCN_SCRATCH_BUDGET floats per
-// activation buffer whatever B is -- 4096 x 65 536 x 32 ch took two 34.4 GB buffers as one launch set, and the per-GPU
-// shapes of BASELINE configs[4] (B >= 8192) did not fit at all.  Chunks are equal-sized (the last may be smaller).
-static const int64_t TCN_SCRATCH_BUDGET = 1000000000;      // floats per activation buffer (4 GB); two buffers
+// The batch is processed in chunks of streams (streams are independent): the scratch is bounded by TCN_SCRATCH_BUDGET floats
+// whatever B is -- 4096 x 65 536 x 32 ch took two 34.4 GB buffers as one launch set, and the per-GPU shapes of BASELINE
+// configs[4] (B >= 8192) did not fit at all.  A batch that needs more than one chunk runs on TWO lanes: chunk k goes to lane
+// k & 1, each lane has its own pair of activation buffers and its own HIP stream (forked from / joined to the caller's
+// stream by events, created and destroyed inside the call), so the drain of one chunk's launch is filled by the other
+// lane's launch and the HBM-bound first block of one chunk runs under the matrix-pipe blocks of the other.  Chunks are
+// equal-sized (the last may be smaller).
+static const int64_t TCN_SCRATCH_BUDGET = 2000000000;      // floats in total (8 GB): 2 lanes x 2 activation buffers
 static int64_t tcn_chunk_streams(int64_t B, int64_t T, int C)
 {
-    int64_t most = TCN_SCRATCH_BUDGET / (T * (int64_t)C);
+    const int64_t per = T * (int64_t)C;
+    if (B * per <= TCN_SCRATCH_BUDGET / 2) return B;       // one chunk, two buffers, the caller's stream
+    int64_t most = TCN_SCRATCH_BUDGET / 4 / per;
     if (most < 1) most = 1;                                // one stream longer than the budget: that stream alone
-    if (B <= most) return B;
     const int64_t chunks = (B + most - 1) / most;
     return (B + chunks - 1) / chunks;
-}
-
-int64_t ntm_tcn_scratch_floats(int64_t B, int64_t T, int C)
-{
-    if (B <= 0 || T <= 0 || C <= 0) return 0;
-    return 2 * (tcn_chunk_streams(B, T, C) * T * (int64_t)C + 16 * (int64_t)C);      // two activation buffers, each padded by one 16-row block
 }
 
 int64_t ntm_tcn_chunk_streams(int64_t B, int64_t T, int C)
 {
     if (B <= 0 || T <= 0 || C <= 0) return 0;
     return tcn_chunk_streams(B, T, C);
+}
+
+int64_t ntm_tcn_scratch_floats(int64_t B, int64_t T, int C)
+{
+    if (B <= 0 || T <= 0 || C <= 0) return 0;
+    const int64_t bc = tcn_chunk_streams(B, T, C);
+    // per lane: two activation buffers, each padded by one 16-row block; two lanes when the batch is chunked
+    return (bc < B ? 2 : 1) * 2 * (bc * T * (int64_t)C + 16 * (int64_t)C);
 }
 
 int ntm_tcn_forward(const float *params, int L, int C, int K, const int *dil, const float *x, float *y, int64_t B,
@@ -463,12 +469,37 @@ int ntm_tcn_forward(const float *params, int L, int C, int K, const int *dil, co
     for (int l = 0; l < L; ++l)
         if (dil[l] <= 0 || dil[l] > (1 << 20)) return fail(NTM_EINVAL, "ntm_tcn_forward: dilations must lie in [1, 2^20]");
     const int64_t bc = tcn_chunk_streams(B, T, C);
-    for (int64_t b0 = 0; b0 < B; b0 += bc) {
-        const int64_t n = B - b0 < bc ? B - b0 : bc;
-        hipError_t e = ntm::launch_tcn(params, L, C, K, dil, x + b0 * T, y + b0 * T, n, T, scratch, (hipStream_t)stream);
-        if (e != hipSuccess) return hip_fail(e, "ntm_tcn_forward");
+    hipStream_t user = (hipStream_t)stream;
+    if (bc >= B) {
+        hipError_t e = ntm::launch_tcn(params, L, C, K, dil, x, y, B, T, scratch, user);
+        return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_tcn_forward");
     }
-    return NTM_OK;
+    // two lanes; everything created here is released before returning (destroying a stream / event with work pending
+    // is legal: the runtime frees it when that work has completed)
+    const int64_t lane_floats = 2 * (bc * T * (int64_t)C + 16 * (int64_t)C);
+    hipStream_t lane[2] = {nullptr, nullptr};
+    hipEvent_t fork = nullptr, done[2] = {nullptr, nullptr};
+    hipError_t e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipStreamCreateWithFlags(&lane[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventRecord(fork, user);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamWaitEvent(lane[i], fork, 0);
+    int k = 0;
+    for (int64_t b0 = 0; b0 < B && e == hipSuccess; b0 += bc, ++k) {
+        const int64_t n = B - b0 < bc ? B - b0 : bc;
+        e = ntm::launch_tcn(params, L, C, K, dil, x + b0 * T, y + b0 * T, n, T, scratch + (k & 1) * lane_floats, lane[k & 1]);
+    }
+    for (int i = 0; i < 2; ++i) {              // join -- also after an error, so that nothing outlives the caller's ordering
+        if (lane[i] && done[i] && hipEventRecord(done[i], lane[i]) == hipSuccess) (void)hipStreamWaitEvent(user, done[i], 0);
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (done[i]) (void)hipEventDestroy(done[i]);
+        if (lane[i]) (void)hipStreamDestroy(lane[i]);
+    }
+    if (fork) (void)hipEventDestroy(fork);
+    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_tcn_forward");
 }
 
 }  // extern "C"

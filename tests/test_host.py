@@ -40,12 +40,13 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
 def test_cabi_pure_host_entry_points():
     L = ntm_amd._lib.lib()
     assert L.ntm_tcn_scratch_floats(2, 100, 32) == 2 * (2 * 100 * 32 + 16 * 32)      # two activation buffers + one row block of padding each
-    # the TCN scratch is bounded for any batch: chunks of streams, <= 1e9 floats per activation buffer (round 3: 2 x 34.4 GB at
+    # the TCN scratch is bounded for any batch: chunks of streams on two lanes, <= 2e9 floats in all (round 3: 2 x 34.4 GB at
     # 4096 x 65536, nothing at all from 8192 streams up)
-    assert L.ntm_tcn_chunk_streams(2, 100, 32) == 2 and L.ntm_tcn_chunk_streams(4096, 65536, 32) == 456
+    assert L.ntm_tcn_chunk_streams(2, 100, 32) == 2 and L.ntm_tcn_chunk_streams(4096, 65536, 32) == 228
     for B in (4096, 8192, 16384, 32768):
         bc = L.ntm_tcn_chunk_streams(B, 65536, 32)
-        assert bc * 65536 * 32 <= 10**9 and L.ntm_tcn_scratch_floats(B, 65536, 32) == 2 * (bc * 65536 * 32 + 512) <= 2.0e9 + 1024
+        assert 4 * bc * 65536 * 32 <= 2 * 10**9 and L.ntm_tcn_scratch_floats(B, 65536, 32) == 4 * (bc * 65536 * 32 + 512) <= 2.0e9 + 2048
+    assert L.ntm_tcn_chunk_streams(200, 65536, 32) == 200 and L.ntm_tcn_scratch_floats(200, 65536, 32) == 2 * (200 * 65536 * 32 + 512)
     assert L.ntm_tcn_chunk_streams(3, 1 << 28, 32) == 1            # one stream longer than the budget: that stream alone
     # argument validation happens before anything touches a device
     assert L.ntm_gru_forward(None, None, None, None, None, None, 24, None, None, 1, 1, 1, 1, None, None) == -1

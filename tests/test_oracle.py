@@ -342,45 +342,49 @@ def test_g18_validate_batched_inference():
 
 
 # ----------------------------------------------------------------------------- round 4: every shipped checkpoint, the harness' shapes
-def _bar(y, ref32, y64):
-    """tests/test_gpu_round4.py's bar: 1e-5 against the reference, or -- where the reference's own fp32 result is further
-    than 2e-6 from the fp64 evaluation of the same network -- as close to that fp64 truth as the reference is."""
+def _bar(y, ref32, y64, gate_noise):
+    """tests/test_gpu_round4.py's bar: 1e-5 against the reference; where the checkpoint's OWN measures -- twice the
+    reference's fp32-vs-fp64 error, or the output change under 1-ulp gate noise (golden `*_gate_noise`) -- exceed 1e-5,
+    as close to the fp64 truth as those measures."""
     d32 = float(np.abs(y - ref32).max())
-    s = float(np.abs(ref32.astype(np.float64) - y64).max())
-    ok = d32 < 1e-5 if s <= 2e-6 else (d32 < 1e-5 or float(np.abs(y - y64).max()) <= 2.0 * s)
-    return ok, d32, s
+    own = max(2.0 * float(np.abs(ref32.astype(np.float64) - y64).max()), float(np.max(gate_noise)))
+    ok = d32 < 1e-5 if own <= 1e-5 else (d32 < 1e-5 or float(np.abs(y - y64).max()) <= own)
+    return ok, d32, own
 
 
 def test_oracle_against_every_shipped_checkpoint_g19():
     """The C restatement against the reference's predict() for all 32 distinct best.pth (44 names), GRU and DiffDelGRU at
-    the toy and the real-tape delay length; teacher-forced from the reference's warm state the 1e-5 bar holds for ALL of them."""
+    the toy and the real-tape delay length; teacher-forced from the reference's warm state the 1e-5 bar holds for every GRU."""
     g = load("g19_checkpoints.npz")
     names, nf = [str(n) for n in g["names"]], [str(f) for f in g["name_file"]]
     assert len(names) == 44 and len(set(nf)) == 32
     xl = (g["x_int16"].astype(np.float32) / 32768.0)[None]
     T = int(g["T"])
-    self_noise = {}
+    own = {}
     for f in sorted(set(nf)):
         name, k = names[nf.index(f)], f[:-4]
         w = oracle_weights(name)
+        gn = g[k + "_gate_noise"]
         if name.startswith("GRU"):
             y, _ = oracle.gru_predict(w, xl[:, :T])
-            ok, d32, s = _bar(y[0], g[k + "_y"], g[k + "_y64"].astype(np.float64))
-            assert ok, (name, d32, s)
-            self_noise[k] = s
+            ok, d32, own[k] = _bar(y[0], g[k + "_y"], g[k + "_y64"].astype(np.float64), gn)
+            assert ok, (name, d32, own[k])
             yt, _ = oracle.gru_forward(w, xl[:, :T], h=g[k + "_hwarm"][None].copy())
             assert np.abs(yt[0] - g[k + "_y"]).max() < 1e-5, name
         else:
             y, pre, _, _ = oracle.diffdel_predict(w, xl[:, :T], g["d_toy"][None], int(g["max_delay_toy"]))
-            assert _bar(y[0], g[k + "_y"], g[k + "_y64"].astype(np.float64))[0], name
-            assert _bar(pre[0], g[k + "_pre"], g[k + "_pre64"].astype(np.float64))[0], name
+            assert _bar(y[0], g[k + "_y"], g[k + "_y64"].astype(np.float64), gn)[0], name
+            ok, _, own[k] = _bar(pre[0], g[k + "_pre"], g[k + "_pre64"].astype(np.float64), gn)
+            assert ok, name
             if k + "_y_real" in g.files:
                 y, pre, _, _ = oracle.diffdel_predict(w, xl, g["d_real"][None], int(g["max_delay_real"]))
-                assert _bar(y[0], g[k + "_y_real"], g[k + "_y64_real"].astype(np.float64))[0], name
-                assert _bar(pre[0], g[k + "_pre_real"], g[k + "_pre64_real"].astype(np.float64))[0], name
-    # GRU-...-L[DCPreESR]-DS[...CHOWTAPE]_1 (w19): its zero-input warm-up amplifies rounding -- the reference's fp32 predict
-    # is 1.5e-2 away from its own fp64 evaluation; every other GRU checkpoint reproduces itself to < 1e-5 on this input
-    assert self_noise.pop("w19") > 1e-3 and max(self_noise.values()) < 1e-5
+                assert _bar(y[0], g[k + "_y_real"], g[k + "_y64_real"].astype(np.float64), g[k + "_gate_noise_real"])[0], name
+                assert _bar(pre[0], g[k + "_pre_real"], g[k + "_pre64_real"].astype(np.float64), g[k + "_gate_noise_real"])[0], name
+    # the ill-conditioned ones, by the goldens' own measures: GRU-...-L[DCPreESR]-DS[...CHOWTAPE]_1 (w19: 1.5e-2, its zero-input
+    # warm-up), DiffDelGRU-...-L[ESR]-DS[...AKAI...]_3 (w11: 2.7e-5); marginally ..._1 (w9: 1.3e-5 in the worst of 32 draws) and
+    # GRU-...-L[DCPreESR]-DS[...AKAI...]_3 (w18: the reference is 5.1e-6 from its own fp64 evaluation); the other 28 allow the plain 1e-5
+    assert sorted(k for k, v in own.items() if v > 1e-5) == ["w11", "w18", "w19", "w9"]
+    assert sorted(k for k, v in own.items() if v > 1.5e-5) == ["w11", "w19"]
 
 
 def test_oracle_at_the_harness_operating_point_g20():
@@ -388,12 +392,13 @@ def test_oracle_at_the_harness_operating_point_g20():
     x = (g["gru_x_int16"].astype(np.float32) / 32768.0)[None]
     for tag in ("chow", "akai"):
         y, _ = oracle.gru_predict(oracle_weights(str(g[f"gru_{tag}_weights"])), x)
-        ok, d32, s = _bar(y[0], g[f"gru_{tag}_y"], g[f"gru_{tag}_y64"].astype(np.float64))
-        assert ok, (tag, d32, s)
-        assert (tag == "chow") == (s <= 2e-6)      # the AKAI checkpoint drifts 2.9e-5 from its own fp64 evaluation inside 10 s
+        ok, d32, own = _bar(y[0], g[f"gru_{tag}_y"], g[f"gru_{tag}_y64"].astype(np.float64), g[f"gru_{tag}_gate_noise"])
+        assert ok, (tag, d32, own)
+        assert (tag == "chow") == (own <= 1e-5)    # the AKAI checkpoint drifts 2.9e-5 from its own fp64 evaluation inside 10 s
     for tag in ("toy", "real"):
         x = (g[f"dd_{tag}_x_int16"].astype(np.float32) / 32768.0)[None]
         y, pre, h, buf = oracle.diffdel_predict(oracle_weights(str(g[f"dd_{tag}_weights"])), x, g[f"dd_{tag}_d"][None],
                                                int(g[f"dd_{tag}_max_delay"]))
         assert np.abs(y[0] - g[f"dd_{tag}_y"]).max() < 1e-5 and np.abs(pre[0] - g[f"dd_{tag}_pre"]).max() < 1e-5
         assert np.abs(buf[0] - g[f"dd_{tag}_buffer"]).max() < 1e-5
+        assert g[f"dd_{tag}_gate_noise"].max() < 1e-5

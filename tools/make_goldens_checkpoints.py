@@ -120,6 +120,36 @@ def f64_truth(name, x, d=None, max_delay=None):
     return wa * xp[i] + wb * xp[np.maximum(i - 1, 0)], pre
 
 
+def gate_noise(name, x, seeds=32):
+    """How far 1-ulp rounding noise in the GATES moves this checkpoint's output: the network's own equations
+    (code/model.py:81-82 = torch.nn.GRU + Linear, restated in float64) with every gate value perturbed by what a float32
+    sigmoid / tanh accurate to about one unit in the last place carries -- r, z relative U(-1,1) 2^-23, n absolute U(-1,1) 2^-23
+    (rms 7e-8: the measured rms of exp2 -> 1 + e -> rcp on fp32 hardware units) -- 1024 zero samples then x, `seeds` independent draws.
+    -> max |y_perturbed - y| per draw.  A property of the checkpoint (and input), not of any implementation: where it exceeds
+    1e-5 no float32 implementation with 1-ulp transcendentals can be expected within 1e-5 of another one."""
+    sd = {k: v.double().numpy() for k, v in mg.load_sd(name).items()}
+    Wih, Whh = sd["GRU.weight_ih_l0"][:, 0], sd["GRU.weight_hh_l0"]
+    bih, bhh, wo = sd["GRU.bias_ih_l0"], sd["GRU.bias_hh_l0"], sd["output.weight"][0]
+    H = Whh.shape[1]
+    rng = np.random.default_rng(2323)
+    xx = np.concatenate([np.zeros(1024), np.asarray(x, np.float64).reshape(-1)])
+    U = 2.0 ** -23
+    h = np.zeros((seeds + 1, H))                       # row 0: unperturbed
+    ys = np.empty((seeds + 1, xx.size))
+    mask = np.ones((seeds + 1, 1)); mask[0] = 0.0
+    WT = Whh.T.copy()
+    for t, xv in enumerate(xx):
+        gh = h @ WT + bhh
+        gi = xv * Wih + bih
+        e = rng.uniform(-U, U, (3, seeds + 1, H)) * mask
+        r = (1.0 / (1.0 + np.exp(-(gi[:H] + gh[:, :H])))) * (1.0 + e[0])
+        z = (1.0 / (1.0 + np.exp(-(gi[H:2 * H] + gh[:, H:2 * H])))) * (1.0 + e[1])
+        n = np.tanh(gi[2 * H:] + r * gh[:, 2 * H:]) + e[2]
+        h = (h - n) * z + n
+        ys[:, t] = h @ wo
+    return np.abs(ys[1:, 1024:] - ys[0, 1024:]).max(axis=1).astype(np.float32)
+
+
 def ref_batch_noise(name, x):
     """max |row of a B = 3 forward - the B = 1 forward| of the REFERENCE model itself (same torch, same thread count):
     how far the reference is from reproducing itself."""
@@ -157,6 +187,7 @@ def g19(manifest):
                 out[f"{f[:-4]}_hwarm"] = m.hidden.numpy()[0, 0].copy()
                 out[f"{f[:-4]}_y64"] = f64_truth(name, x[:, :, :T]).astype(np.float32)
                 out[f"{f[:-4]}_b3"] = ref_batch_noise(name, x[:, :, :T])
+                out[f"{f[:-4]}_gate_noise"] = gate_noise(name, x[:, :, :T])
             else:
                 m = mg.make_ddr(name, 1846)
                 y, pre = m.predict(torch.from_numpy(x[:, :, :T]), torch.from_numpy(d_toy))
@@ -167,6 +198,7 @@ def g19(manifest):
                 out[f"{f[:-4]}_bwarm"] = m.diffdel.buffer.numpy()[0, 0, -1024:].copy()     # the rest of the buffer is zero
                 y64, p64 = f64_truth(name, x[:, :, :T], d_toy, 1846)
                 out[f"{f[:-4]}_y64"], out[f"{f[:-4]}_pre64"] = y64.astype(np.float32), p64.astype(np.float32)
+                out[f"{f[:-4]}_gate_noise"] = gate_noise(name, x[:, :, :T])
                 if "AKAI" in name:
                     m = mg.make_ddr(name, 11000)
                     y, pre = m.predict(torch.from_numpy(x), torch.from_numpy(d_real))
@@ -174,6 +206,7 @@ def g19(manifest):
                     assert m.diffdel.max_delay == 11001
                     y64, p64 = f64_truth(name, x, d_real, 11000)
                     out[f"{f[:-4]}_y64_real"], out[f"{f[:-4]}_pre64_real"] = y64.astype(np.float32), p64.astype(np.float32)
+                    out[f"{f[:-4]}_gate_noise_real"] = gate_noise(name, x)
             print(f"  g19 {f} {name[:60]}  {time.time() - t0:.1f}s", flush=True)
     np.savez_compressed(os.path.join(mg.GDIR, "g19_checkpoints.npz"), **out)
 
@@ -195,6 +228,7 @@ def g20():
             out[f"gru_{tag}_y"] = mg.make_rnn(name).predict(x).numpy()[0, 0]
             out[f"gru_{tag}_y64"] = f64_truth(name, x.numpy()).astype(np.float32)
             out[f"gru_{tag}_b3"] = ref_batch_noise(name, x.numpy())
+            out[f"gru_{tag}_gate_noise"] = gate_noise(name, x.numpy(), seeds=16)
             print(f"  g20 GRU {tag} T={T}  {time.time() - t0:.1f}s", flush=True)
         # DiffDelGRU, toy delay length at the bench's sequence length
         T2 = 65536
@@ -205,7 +239,8 @@ def g20():
         y, pre = m.predict(torch.from_numpy((x2_16.astype(np.float32) / 32768.0).reshape(1, 1, T2)),
                            torch.from_numpy(d2.reshape(1, 1, T2)))
         y64, p64 = f64_truth(mg.W_D, (x2_16.astype(np.float32) / 32768.0).reshape(1, 1, T2), d2, 1846)
-        out.update(dd_toy_y64=y64.astype(np.float32), dd_toy_pre64=p64.astype(np.float32))
+        out.update(dd_toy_y64=y64.astype(np.float32), dd_toy_pre64=p64.astype(np.float32),
+                   dd_toy_gate_noise=gate_noise(mg.W_D, x2_16.astype(np.float32) / 32768.0, seeds=16))
         out.update(dd_toy_weights=mg.W_D, dd_toy_max_delay=1846, dd_toy_x_int16=x2_16, dd_toy_d=d2,
                    dd_toy_y=y.numpy()[0, 0], dd_toy_pre=pre.numpy()[0, 0],
                    dd_toy_buffer=m.diffdel.buffer.numpy()[0, 0].copy(), dd_toy_hidden=m.hidden.numpy()[0, 0].copy())
@@ -219,7 +254,8 @@ def g20():
         y, pre = m.predict(torch.from_numpy((x3_16.astype(np.float32) / 32768.0).reshape(1, 1, T3)),
                            torch.from_numpy(d3.reshape(1, 1, T3)))
         y64, p64 = f64_truth(W_D_AKAI, (x3_16.astype(np.float32) / 32768.0).reshape(1, 1, T3), d3, 11000)
-        out.update(dd_real_y64=y64.astype(np.float32), dd_real_pre64=p64.astype(np.float32))
+        out.update(dd_real_y64=y64.astype(np.float32), dd_real_pre64=p64.astype(np.float32),
+                   dd_real_gate_noise=gate_noise(W_D_AKAI, x3_16.astype(np.float32) / 32768.0, seeds=16))
         out.update(dd_real_weights=W_D_AKAI, dd_real_max_delay=11000, dd_real_x_int16=x3_16, dd_real_d=d3,
                    dd_real_y=y.numpy()[0, 0], dd_real_pre=pre.numpy()[0, 0],
                    dd_real_buffer=m.diffdel.buffer.numpy()[0, 0].copy(), dd_real_hidden=m.hidden.numpy()[0, 0].copy())
