@@ -333,7 +333,7 @@ def test_bench_spawns_its_own_ranks_on_one_gpu_over_gloo():
         assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["backend"] == "gloo" and out["rccl_ranks"] == 0
         assert [d["rank"] for d in out["rank_devices"]] == [0, 1]
         assert out["config"]["segments_total"] == total and out["checks"]["segments"] == total
-        assert out["checks"]["esr_vs_first_pass"] == 0.0
+        assert out["checks"]["job_esr"] > 0 and out["checks"]["last_output_equals_first_pass_bitwise"] is True
         assert out["scaling"] == ("strong" if "--scaling" in extra else "weak")
         assert abs(out["value"] - total * 4096 * 2 / (out["ms_per_step"] * 2e-3)) < 1e-6 * out["value"]
 
@@ -356,7 +356,7 @@ def test_bench_one_rank_process_group_runs_the_rccl_calls():
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert out["backend"].startswith("rccl") and out["rccl_ranks"] == 1 and out["ranks"] == 1
     assert out["rank_devices"][0]["rank"] == 0 and out["rank_devices"][0]["device"] == 0
-    assert out["checks"]["segments"] == 512 and out["checks"]["esr_vs_first_pass"] == 0.0
+    assert out["checks"]["segments"] == 512 and out["checks"]["job_esr"] > 0 and out["checks"]["last_output_equals_first_pass_bitwise"] is True
     assert out["checks"]["every_timed_step_same_loss"] is True
 
 

@@ -308,3 +308,45 @@ def test_tcn_stream_chunks_bit_identical_and_bounded(ntm):
     y3 = tcn(x[:3])                                    # 3 streams: one chunk
     assert torch.equal(y3, y[:3])
     assert L.ntm_tcn_scratch_floats(32768, 65536, 32) <= 2 * 10**9 + 2048 >= L.ntm_tcn_scratch_floats(4096, 65536, 32)
+
+
+# ----------------------------------------------------------------------------- BASELINE configs[4] at its real shapes, on the one GPU
+FULL = pytest.mark.skipif(os.environ.get("NTM_SKIP_FULL") == "1", reason="full-size passes skipped on request")
+
+
+def _bench(args, **env_extra):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+@FULL
+def test_full_size_eight_rank_dry_run_on_one_gpu():
+    """The first time BASELINE configs[4]'s REAL shapes meet the launcher must not be on the driver's 8-GPU node: eight ranks
+    x 4096 x 65 536 (weak: 32 768 segments) and four ranks x 8192 (strong: --total-batch 32768), all sharing this box's GPU
+    over gloo (8 x 4.4 GB resident).  Rank/device table, segment totals, the job ESR: identical to the one-rank value when
+    every rank holds the same data... they do not (one seed per 4096-segment block), so the weak job's ESR is checked against
+    the strong job's, which shards the SAME 32 768 segments differently.  Reference counterpart: none (replicas only)."""
+    common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--other", "off", "--traffic", "off"]
+    weak = _bench(["--gpus", "8"] + common, NTM_DIST_BACKEND="gloo")
+    assert weak["n_gpus"] == 8 and weak["ranks"] == 8 and weak["backend"] == "gloo" and weak["rccl_ranks"] == 0
+    assert [d["rank"] for d in weak["rank_devices"]] == list(range(8)) and all(d["device"] == 0 for d in weak["rank_devices"])
+    assert weak["config"]["segments_total"] == 32768 == weak["checks"]["segments"] and weak["config"]["segments_rank0"] == 4096
+    assert weak["checks"]["job_esr"] > 0 and weak["checks"]["every_timed_step_same_loss"] is True
+    assert weak["checks"]["last_output_equals_first_pass_bitwise"] is True and weak["scaling"] == "weak"
+    assert abs(weak["value"] - 32768 * 65536 / (weak["ms_per_step"] * 1e-3)) < 1e-6 * weak["value"]
+    strong = _bench(["--gpus", "4", "--scaling", "strong", "--total-batch", "32768"] + common, NTM_DIST_BACKEND="gloo")
+    assert strong["ranks"] == 4 and strong["config"]["segments_total"] == 32768 and strong["config"]["segments_rank0"] == 8192
+    assert strong["checks"]["segments"] == 32768 and strong["scaling"] == "strong"
+    one = _bench(["--gpus", "1"] + common)
+    assert one["checks"]["segments"] == 4096 and one["rccl_ranks"] == 0 and one["backend"].startswith("none")
+    # rank 0 of the weak job holds exactly the one-rank job's data: the per-rank part of the loss must agree; the job-wide
+    # sums are sums over ranks, so the weak job's err^2 is larger than one rank's
+    assert weak["checks"]["job_sum_err2"] > one["checks"]["job_sum_err2"] > 0
+    assert weak["checks"]["stream0_vs_reference_max_abs"] == one["checks"]["stream0_vs_reference_max_abs"] < TOL
