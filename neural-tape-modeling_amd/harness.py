@@ -9,8 +9,9 @@ from .model import RNN, DiffDelRNN, MRSTFTLoss, esr_dcpre_sums, esr_sums, ESR_EP
 from .utilities import nextpow2, parse_hidden_size, parse_loss, parse_model
 
 
-def build_model(weight_name, max_delay_seconds=0.0, fs=44100, device="cuda", state_dict=None):
-    """code/test-model.py:197-233: parse the directory name, construct, load best.pth."""
+def build_model(weight_name, max_delay_seconds=0.0, fs=44100, device="cuda", state_dict=None, warm_cache=True):
+    """code/test-model.py:197-233: parse the directory name, construct, load best.pth.  The evaluation path never touches the
+    parameters again, so the warm-start state is kept per parameter version (`warm_cache`, model.py's docstring)."""
     hidden_size = parse_hidden_size(weight_name)
     model_type = parse_model(weight_name)
     parse_loss(weight_name)                     # raises on a malformed name, as the reference would
@@ -25,7 +26,9 @@ def build_model(weight_name, max_delay_seconds=0.0, fs=44100, device="cuda", sta
     else:
         raise SystemExit('Something is not right!')               # code/test-model.py:232
     model.load_state_dict(state_dict if state_dict is not None else weights.load_state_dict(weight_name))
-    return model.to(device).eval()
+    model = model.to(device).eval()
+    model.warm_cache = bool(warm_cache)
+    return model
 
 
 def init_len(max_delay_seconds, fs=44100):

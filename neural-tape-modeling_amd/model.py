@@ -15,12 +15,15 @@ Deliberate differences from the reference (documented in DESIGN.md):
   * validate() (code/model.py:163-216, :513-616 -- the reference's own batched, inference-only use of forward,
     called by code/train.py:242) and detach_hidden / detach_buffer are here; train_epoch (backward) is out of
     scope.
-  * warm_start() from a fresh state is a pure function of the parameters: its result (hidden state; for the
-    DiffDelGRU also the delay buffer) is computed by the kernel ONCE per (parameter version, device, kernel variant,
-    delay-line length) and kept, so a predict() is one launch instead of two.  Same numbers as recomputing it
-    (code/model.py:58-65, :382-391 recompute it every time); `warm_cache = False` turns the cache off,
-    `invalidate_warm_cache()` drops it (needed only after writing parameters through `.data`, which by-passes
-    torch's version counters).
+  * warm_start() from a fresh state is a pure function of the parameters.  With `warm_cache = True` its result (hidden
+    state; for the DiffDelGRU also the delay buffer) is computed by the kernel ONCE per (parameter storage + torch version
+    counter, device, kernel variant, delay-line length) and kept, so a predict() is one launch instead of two -- same numbers
+    as recomputing it (code/model.py:58-65, :382-391 recompute it every time).  The class default is OFF (every predict()
+    recomputes, exactly the reference's behaviour): torch's version counters see load_state_dict, `.to()`, and every in-place
+    op on the Parameter, but NOT writes through `.data` (`p.data.mul_()`, `p.data.copy_()`) -- a cache keyed on them would
+    serve a stale state there without any error.  harness.build_model() turns the cache ON for the evaluation path
+    (code/test-model.py:192-247: construct, load best.pth, .eval(), never touched again) and bench.py reports the step both
+    ways; whoever enables it elsewhere and writes through `.data` calls `invalidate_warm_cache()` (tests/test_gpu_round4.py).
 """
 import numpy as np
 import torch
@@ -79,7 +82,7 @@ class _GRUHead(torch.nn.Module):
     # product kernels (libntm.so): "auto" | "mfma2" | "lat" | "f16x3" (opt-in);  laboratory kernels for A/B and as
     # independent implementations in the tests (libntm_lab.so): "mfma" | "valu" | "mfma3" | "mfma4"  (NTM_GRU_*)
     kernel_variant = "auto"
-    warm_cache = True          # keep the warm-start state per parameter version (see the module docstring)
+    warm_cache = False         # True: keep the warm-start state per parameter version (module docstring; harness.build_model turns it on)
 
     def _warm_key(self, *extra):
         """Identity of everything warm_start() depends on: the parameter tensors (storage + torch version counter,

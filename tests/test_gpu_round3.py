@@ -150,6 +150,8 @@ def test_warm_start_cache_is_bit_identical_and_follows_the_parameters(ntm):
     md = ntm.DiffDelRNN(1, 64, 1, max_delay=300)
     md.load_state_dict(ntm.weights.load_state_dict(W_D))
     md = md.to("cuda").eval()
+    assert md.warm_cache is False                 # the class default: recompute, like the reference
+    md.warm_cache = True
     rng = np.random.default_rng(3)
     xd = dev(rng.uniform(-0.5, 0.5, (2, 1, 3000)).astype(np.float32))
     dd = dev((150 + 100 * np.sin(np.arange(3000) / 200.0))[None, None, :].repeat(2, 0).astype(np.float32))

@@ -330,9 +330,10 @@ def _bench(args, **env_extra):
 def test_full_size_eight_rank_dry_run_on_one_gpu():
     """The first time BASELINE configs[4]'s REAL shapes meet the launcher must not be on the driver's 8-GPU node: eight ranks
     x 4096 x 65 536 (weak: 32 768 segments) and four ranks x 8192 (strong: --total-batch 32768), all sharing this box's GPU
-    over gloo (8 x 4.4 GB resident).  Rank/device table, segment totals, the job ESR: identical to the one-rank value when
-    every rank holds the same data... they do not (one seed per 4096-segment block), so the weak job's ESR is checked against
-    the strong job's, which shards the SAME 32 768 segments differently.  Reference counterpart: none (replicas only)."""
+    over gloo (8 x 5.4 GB resident), next to the one-rank job.  Checked: rank/device table, segment totals, throughput
+    arithmetic, non-zero job ESR identical in every timed step, bitwise determinism of the output; rank 0 of the weak job holds
+    the one-rank job's data (stream 0 = golden g6 against the REFERENCE's output, same number in both).
+    Reference counterpart: none (scripts/sbatch-train-exp1a.sh:7 runs replicas only)."""
     common = ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--other", "off", "--traffic", "off"]
     weak = _bench(["--gpus", "8"] + common, NTM_DIST_BACKEND="gloo")
     assert weak["n_gpus"] == 8 and weak["ranks"] == 8 and weak["backend"] == "gloo" and weak["rccl_ranks"] == 0
@@ -350,3 +351,39 @@ def test_full_size_eight_rank_dry_run_on_one_gpu():
     # sums are sums over ranks, so the weak job's err^2 is larger than one rank's
     assert weak["checks"]["job_sum_err2"] > one["checks"]["job_sum_err2"] > 0
     assert weak["checks"]["stream0_vs_reference_max_abs"] == one["checks"]["stream0_vs_reference_max_abs"] < TOL
+
+
+def test_warm_cache_contract_under_data_writes(ntm):
+    """The warm-start cache is keyed on torch's version counters, which writes through `.data` by-pass.  Contract: the class
+    default is OFF (a model built by hand always recomputes: `.data` writes are seen), harness.build_model turns it ON for the
+    evaluation path, and there a `.data` write needs invalidate_warm_cache() -- shown here both ways against the oracle."""
+    import oracle
+    from helpers import state_dict_np
+    W_G = "GRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE]_BEST"
+    rng = np.random.default_rng(8)
+    x = rng.uniform(-0.5, 0.5, (2, 600)).astype(np.float32)
+
+    def want(scale):
+        sd = state_dict_np(W_G)
+        sd["GRU.bias_hh_l0"] = (sd["GRU.bias_hh_l0"] * np.float32(scale)).astype(np.float32)
+        return oracle.gru_predict(oracle.Weights.from_state_dict(sd), x)[0]
+
+    by_hand = build(ntm, W_G)
+    assert by_hand.warm_cache is False
+    assert np.abs(by_hand.predict(dev(x).unsqueeze(1)).cpu().numpy()[:, 0] - want(1.0)).max() < TOL
+    by_hand.GRU.bias_hh_l0.data.mul_(1.5)                         # a write torch's version counter does not see
+    assert np.abs(by_hand.predict(dev(x).unsqueeze(1)).cpu().numpy()[:, 0] - want(1.5)).max() < TOL and by_hand._warm is None
+
+    cached = ntm.harness.build_model(W_G)
+    assert cached.warm_cache is True
+    cached.predict(dev(x).unsqueeze(1))
+    v = cached.GRU.bias_hh_l0._version
+    cached.GRU.bias_hh_l0.data.mul_(1.5)
+    assert cached.GRU.bias_hh_l0._version == v                    # ... which is why the key cannot follow it
+    stale = cached.predict(dev(x).unsqueeze(1)).cpu().numpy()[:, 0]
+    assert np.abs(stale - want(1.5)).max() > 1e-4                 # new weights, OLD warm state: the documented failure
+    cached.invalidate_warm_cache()
+    assert np.abs(cached.predict(dev(x).unsqueeze(1)).cpu().numpy()[:, 0] - want(1.5)).max() < TOL
+    with torch.no_grad():
+        cached.GRU.bias_hh_l0.mul_(1.0 / 1.5)                     # an in-place op on the Parameter itself IS seen
+    assert np.abs(cached.predict(dev(x).unsqueeze(1)).cpu().numpy()[:, 0] - want(1.0)).max() < 2 * TOL

@@ -8,6 +8,13 @@ disassembly of every non-diagnostic instantiation is checked here: walking back 
 h-exchange write (ds_write_b128, or the two ds_write_b64 of the f16x3 engine) there must be exactly one lgkm-counted
 instruction and it must be a ds_write_b32.
 
+Second check (round 4): full drains of the vector-memory counter in the hot loop.  DESIGN.md 4 K2f lists two behaviours of
+hipcc's wait insertion that each exposed a memory round trip per 64-sample tile (a `s_waitcnt vmcnt(0)` in front of a load that
+did not need it: 1 % of the step, silently); the kernel steers around them with __builtin_amdgcn_s_waitcnt at run-time-free
+places.  Whether that still works is a property of the compiler, so the number of `s_waitcnt vmcnt(0)` inside the
+MFMA-richest loop of every product instantiation is pinned to what the measured binary has (MAX_DRAINS); more = this test
+fails on the CPU instead of the bench losing 1 % unnoticed.  Fewer is reported and accepted.
+
 usage: check_barrier_asm.py [gru_mfma2.hip]     (exit status 0 = ok)"""
 import os
 import re
@@ -23,6 +30,32 @@ SRC = sys.argv[1] if len(sys.argv) > 1 else os.path.join(HERE, "..", "neural-tap
 LGKM = re.compile(r"^\s*(ds_|s_load_|s_buffer_load|s_memtime|s_memrealtime|s_sendmsg|s_scratch_load|flat_|scratch_)")
 
 
+# `s_waitcnt vmcnt(0)` in the hot loop (10 unrolled steps) of the binary the round-3/4 profiles were taken from (ROCm 7.2 hipcc),
+# keyed by the template arguments (ENGINE, FUSE, ESR); the same for YPN = 4 and 16
+MAX_DRAINS = {(0, 0, 0): 3, (0, 0, 1): 6, (1, 0, 0): 3, (0, 1, 0): 4, (0, 1, 1): 6}
+
+
+def hot_loop_drains(body):
+    """(number of `s_waitcnt vmcnt(0)`, MFMAs) in the loop of `body` that holds the most MFMAs."""
+    ins, labels = [], {}
+    for ln in body.splitlines():
+        m = re.match(r"\s*(\.LBB\w+):", ln)
+        if m:
+            labels[m.group(1)] = len(ins)
+            continue
+        t = ln.split(";")[0].strip()
+        if t:
+            ins.append(t)
+    best = (0, 0, 0)
+    for i, t in enumerate(ins):
+        m = re.match(r"s_c?branch\w*\s+(\.LBB\w+)", t)
+        if m and labels.get(m.group(1), i + 1) <= i:
+            a = labels[m.group(1)]
+            best = max(best, (sum(1 for u in ins[a:i + 1] if u.startswith("v_mfma")), a, i))
+    mf, a, b = best
+    return sum(1 for t in ins[a:b + 1] if t.startswith("s_waitcnt") and "vmcnt(0)" in t), mf
+
+
 def check(defines=()):
     """Compile SRC with the product flags (+ `defines`) and check every non-diagnostic instantiation."""
     with tempfile.TemporaryDirectory() as tmp:
@@ -34,9 +67,18 @@ def check(defines=()):
     kernels = re.findall(r"^(_ZN3ntm16gru_mfma2_kernel\w+):[^\n]*\n(.*?)\n\s*\.amdhsa_kernel", text, flags=re.S | re.M)
     checked = 0
     for name, body in kernels:
-        m = re.match(r"_ZN3ntm16gru_mfma2_kernelILb1ELb(\d)ELi(\d+)ELi(\d)ELi(\d+)E(?:Lb\dE)*EE", name)
+        m = re.match(r"_ZN3ntm16gru_mfma2_kernelILb1ELb(\d)ELi(\d+)ELi(\d)ELi(\d+)E((?:Lb\dE)*)EE", name)
         if not m or m.group(1) == "1" or m.group(2) != "0":
             continue                                      # STAMP / ablation builds are diagnostics (they use lgkmcnt(0))
+        flags = [int(v) for v in re.findall(r"Lb(\d)E", m.group(5))] + [0, 0]
+        key = (int(m.group(3)), flags[0], flags[1])
+        drains, mf = hot_loop_drains(body)
+        assert mf >= 270, f"{name}: hot loop not found ({mf} MFMAs)"
+        assert key in MAX_DRAINS, f"{name}: instantiation {key} has no pinned drain count"
+        assert drains <= MAX_DRAINS[key], (f"{name}: {drains} x `s_waitcnt vmcnt(0)` in the hot loop, the measured binary has "
+                                           f"{MAX_DRAINS[key]}: hipcc's wait insertion changed (DESIGN.md 4 K2f) -- re-measure")
+        if drains < MAX_DRAINS[key]:
+            print(f"note: {name}: {drains} drains in the hot loop (pinned {MAX_DRAINS[key]})")
         # Instructions in layout order, labels and branches kept as block boundaries.  The step is inlined several times
         # (compile-time housekeeping positions), inside loops and in straight-line runs, so the invariant is checked as
         # two local properties that compose over every path from one step copy to the next:
