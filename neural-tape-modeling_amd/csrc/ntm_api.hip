@@ -231,8 +231,11 @@ static int diffdel_impl(const float *w_ih, const float *w_hh, const float *b_ih,
     }
     if (fused < B) {            // the streams the fused kernel did not take: GRU launch, then the streaming delay pass
         const int64_t r = B - fused, o = fused * T;
-        int rc = ntm_gru_forward(w_ih, w_hh, b_ih, b_hh, w_o, nullptr, H, x + o, pre_d + o, r, T, T, T,
-                                 h_state ? h_state + fused * H : nullptr, stream);
+        // (a warm-up call under NTM_DIFFDEL_FUSED keeps the matrix-pipe GRU kernel the fused launch would have run, so that
+        // the state a forced mode leaves behind does not depend on which calls were warm-ups)
+        const int gv = (warmup && mode == NTM_DIFFDEL_FUSED) ? NTM_GRU_MFMA2 : NTM_GRU_AUTO;
+        int rc = ntm_gru_forward_ex(w_ih, w_hh, b_ih, b_hh, w_o, nullptr, H, x + o, pre_d + o, r, T, T, T,
+                                    h_state ? h_state + fused * H : nullptr, gv, stream);
         if (rc != NTM_OK) return rc;
         if (r <= 0 || T <= 0) return NTM_OK;
         if (!d || !y || (D > 0 && !dl_state)) return fail(NTM_EINVAL, "ntm_delay_forward: null pointer");
