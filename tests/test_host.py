@@ -226,3 +226,17 @@ def test_recorded_bench_line_follows_the_contract():
         v = ow[f"gru_B{b}"]
         flops = 25088.0 * b * 65536
         assert abs(v["roofline"]["achieved"] - flops / (v["kernel_ms"] * 1e-3) / 1e12) < 1e-6 * v["roofline"]["achieved"]
+        # round 4: no `traffic: null` legs -- PMC bytes per launch within 1 % of the 8 algorithmic bytes per sample
+        assert 1.0 <= v["roofline"]["traffic"] / (8.0 * b * 65536) < 1.01 and "pmc_traffic_gru_B" in v["roofline"]["traffic_source"]
+    # round 4: the TCN states what it MOVES (not the 8 B/sample of a fused network), runs at the per-GPU shapes of configs[4] too
+    t = ow["tcn"]
+    assert 700 < t["bytes_per_sample"] < 850 and t["roofline"]["bytes_per_sample_if_fused"] == 8
+    assert t["roofline"]["scratch_bytes"] <= 8.0e9 + 8192 and {"tcn_B8192", "tcn_B16384"} <= set(ow)
+    assert abs(ow["tcn_B8192"]["kernel_ms"] / t["kernel_ms"] - 2.0) < 0.04            # same time per 4096 streams
+    # round 4: the loss leg of the timed step runs against a real target and is checked against the oracle
+    c = d["checks"]
+    assert c["job_esr"] > 1e-4 and c["every_timed_step_same_loss"] is True and c["last_output_equals_first_pass_bitwise"] is True
+    assert c["esr_sums_vs_oracle"]["max_rel"] < 1e-9 and c["esr_sums_vs_oracle"]["esr_max_rel_diff"] < 1e-3
+    assert c["streams_vs_oracle"]["max_abs"] < 1e-5 and c["stream0_vs_reference_max_abs"] < 1e-5
+    assert d["ms_per_step"] <= d["ms_per_step_no_warm_cache"] < 1.03 * d["ms_per_step"]
+    assert d["roofline"]["traffic"] is not None and 1.0 <= d["roofline"]["traffic"] / (12.0 * seg * T) < 1.01
