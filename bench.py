@@ -139,7 +139,7 @@ def profile_traffic(pattern, key):
                         "command, gfx950 correction applied; not re-measured in this run)")
 
 
-def measure_workload(workload, B, T, steps, warmup, check, dev, threads=1, delay_mode="auto"):
+def measure_workload(workload, B, T, steps, warmup, check, dev, threads=1, delay_mode="auto", live=False):
     """One single-GPU workload beside the headline, `steps` timed passes over a resident batch of B distinct streams:
       "diffdel"  BASELINE configs[2]: DiffDelGRU-HS[64] (CHOWTAPE_WOWFLUTTER weights, D = 1847) predict
       "tcn"      BASELINE configs[3]: the TCN contrast point
@@ -236,14 +236,19 @@ def measure_workload(workload, B, T, steps, warmup, check, dev, threads=1, delay
             # the streaming delay pass: 12 more bytes per sample) is timed beside it for the A/B.
             roof["kernel"] = kernel = "gru_mfma2_kernel<FUSE: GRU + head + delay line> (+ delay_update_kernel)"
             roof["hbm_bytes_per_sample"] = 16
-            if (B, T) == (4096, 65536):          # PMC traffic of the fused kernel (tools/pmc_traffic.sh passes)
-                import glob
+            if (B, T) == (4096, 65536):          # PMC traffic of the fused kernel (~1.25 x the algorithmic bytes,
+                import glob                      # the taps come back from beyond L2)
+                why = None
+                if live:                         # two rocprofv3 --pmc child passes of `bench.py --workload diffdel`, in this run
+                    roof["traffic"], why = live_traffic(r"gru_mfma2_kernel<true, false, 0, 0, 16, true, false>",
+                                                        ["--workload", "diffdel", "--batch", str(B), "--samples", str(T)])
+                    roof["traffic_source"] = why
                 files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic_diffdel_fused*.json")))
-                if files:
+                if roof["traffic"] is None and files:
                     roof["traffic"] = json.load(open(files[-1]))["hbm_bytes_per_launch_corrected"]
                     roof["traffic_source"] = ("profiles/" + os.path.basename(files[-1]) + " (rocprofv3 --pmc passes of `bench.py "
-                                              "--workload diffdel`; not re-measured in this run; 1.25 x the algorithmic bytes: "
-                                              "the taps come back from beyond L2)")
+                                              "--workload diffdel`; not re-measured in this run" + (f"; live passes: {why}" if why else "") + ")")
+                roof["algorithmic_bytes"] = 16.0 * B * T
             model.delay_mode = "two_pass"
             t1, g1, d1 = [], [], []
             for i in range(1 + steps):
@@ -314,9 +319,11 @@ def other_workloads(a, dev, check):
     threads = _host_threads()
     jobs = ([(wl, wl, a.batch) for wl in ("diffdel", "tcn")] + [(f"gru_B{b}", "gru", b) for b in a.other_gru_batches]
             + [(f"tcn_B{b}", "tcn", b) for b in a.other_tcn_batches])
+    profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    live = a.traffic == "live" or (a.traffic == "auto" and not profiled)          # never a profiler inside a profiler
     for key, wl, b in jobs:
         try:
-            out[key] = measure_workload(wl, b, a.samples, a.other_steps, 1, check, dev, threads)
+            out[key] = measure_workload(wl, b, a.samples, a.other_steps, 1, check, dev, threads, live=live and key == "diffdel")
         except Exception as e:          # a side workload must never take the headline line down with it (e.g. out of memory
             out[key] = {"error": f"{type(e).__name__}: {e}"[:500]}      # on a box that is shared or smaller than expected)
             torch.cuda.empty_cache()

@@ -215,3 +215,30 @@ def test_sidecar_lookup_is_by_file_name_not_by_id(tmp_path):
     got = {os.path.basename(os.path.dirname(f.input_files[f.examples[i]["idx"]])): float(f[i][2]["delay_trajectory"][0])
            for i in range(len(f))}
     assert abs(got["Train"] - 0.01) < 1e-7 and abs(got["Test"] - 0.02) < 1e-7
+
+
+def test_fraction_and_shuffle_select_examples_like_create_fractional_patches(tmp_path):
+    """code/dataset.py:295-341 for one device configuration: int(len * fraction) examples -- the FIRST ones without shuffling,
+    drawn WITH replacement by np.random.randint when shuffling (repeatable here through `seed`; the global generator, as
+    upstream, without); a fraction that selects nothing raises ValueError; batches / sharding follow the selection."""
+    root, data = make_dataset(str(tmp_path))
+    full = SegmentFeeder(root, subset="test", length=2000)
+    assert len(full) == 5 + 6 + 4
+    half = SegmentFeeder(root, subset="test", length=2000, fraction=0.5)
+    assert len(half) == 7 and [(e["idx"], e["offset"]) for e in half.examples] == [(e["idx"], e["offset"]) for e in full.examples[:7]]
+    a = SegmentFeeder(root, subset="test", length=2000, fraction=0.6, shuffle=True, seed=11)
+    b = SegmentFeeder(root, subset="test", length=2000, fraction=0.6, shuffle=True, seed=11)
+    pick = np.random.RandomState(11).randint(0, high=15, size=9)
+    assert len(a) == 9 and [(e["idx"], e["offset"]) for e in a.examples] == [(full.examples[i]["idx"], full.examples[i]["offset"]) for i in pick]
+    assert [(e["idx"], e["offset"]) for e in a.examples] == [(e["idx"], e["offset"]) for e in b.examples]
+    np.random.seed(5)
+    c = SegmentFeeder(root, subset="test", length=2000, shuffle=True)          # upstream's unseeded draw = the global generator
+    np.random.seed(5)
+    assert [(e["idx"], e["offset"]) for e in c.examples] == [(full.examples[i]["idx"], full.examples[i]["offset"])
+                                                             for i in np.random.randint(0, high=15, size=15)]
+    with pytest.raises(ValueError, match="set too low"):
+        SegmentFeeder(root, subset="test", length=2000, fraction=0.01)
+    # a shuffled selection is not a set of runs of consecutive segments: batches still deliver exactly the selected items
+    got = np.concatenate([x.numpy()[:, 0] for x, _, _, _ in a.batches(4, device="cpu")])
+    want = np.stack([data[e["idx"]][0][e["offset"]:e["offset"] + 2000] for e in a.examples])
+    assert np.array_equal(got, want)
