@@ -238,6 +238,46 @@ def test_fused_diffdel_step_random_shapes_bit_identical_to_two_pass(ntm, B, T, D
     assert np.array_equal(res["fused"][0].cpu().numpy(), yo) and np.array_equal(res["fused"][3][:, 0].cpu().numpy(), bo)
 
 
+@settings(max_examples=30, **SET)
+@given(B=st.integers(1, 24), T=st.integers(1, 3000), D=st.integers(1800, 12000), seed=st.integers(0, 2**31 - 1),
+       cuts=st.lists(st.integers(1, 2999), max_size=2), kind=st.sampled_from(["tape", "sweep", "white", "edge"]))
+def test_fused_diffdel_step_real_tape_delay_lengths(ntm, B, T, D, seed, cuts, kind):
+    """Round 4: the same property at the delay-line lengths the harness builds (code/test-model.py:222-230: D = 1847 for the toy
+    data, about 11 000 for the real tape; round 3 drew D <= 400): every tap of a short call lies in the carried history (T < D),
+    trajectories near the head distance with wow, full-range sweeps, white delays, and the edges d = D / d = 0 / d just below 0."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-0.5, 0.5, (B, T)).astype(np.float32)
+    n = np.arange(T)
+    if kind == "tape":
+        d = D * rng.uniform(0.6, 0.8, (B, 1)) + D * 0.04 * np.sin(2 * np.pi * n[None, :] / rng.uniform(200, 5000, (B, 1)) + rng.uniform(0, 6, (B, 1)))
+    elif kind == "sweep":
+        d = 0.5 * D * (1 + np.sin(2 * np.pi * n[None, :] / rng.uniform(300, 4000, (B, 1)) + rng.uniform(0, 6, (B, 1))))
+    elif kind == "white":
+        d = rng.uniform(-0.9, D, (B, T))
+    else:
+        d = rng.choice(np.array([0.0, -0.5, D, D - 0.25, D - 1.0, 1.0, 0.5 * D]), size=(B, T))
+    d = np.clip(d, -0.9, D).astype(np.float32)
+    h0 = rng.uniform(-0.3, 0.3, (B, 64)).astype(np.float32)
+    b0 = rng.uniform(-0.3, 0.3, (B, D)).astype(np.float32)
+    edges = [0] + sorted({c for c in cuts if c < T}) + [T]
+    res = {}
+    for mode in ("two_pass", "fused"):
+        m = ntm.DiffDelRNN(1, 64, 1, max_delay=D - 1)
+        m.load_state_dict(ntm.weights.load_state_dict(ntm.weights.W_DIFFDEL))
+        m = m.to("cuda").eval()
+        m.delay_mode = mode
+        if mode == "two_pass":
+            m.kernel_variant = "mfma2"
+        m.initialize_hidden(B, D - 1)
+        m.hidden, m.diffdel.buffer = dev(h0).view(1, B, 64), dev(b0).view(B, 1, D)
+        outs = [m(dev(x[:, a:b]).unsqueeze(1), dev(d[:, a:b]).unsqueeze(1)) for a, b in zip(edges, edges[1:])]
+        res[mode] = (torch.cat([o[0] for o in outs], 2)[:, 0], torch.cat([o[1] for o in outs], 2)[:, 0], m.hidden.clone(), m.diffdel.buffer.clone())
+    for a, b, what in zip(res["two_pass"], res["fused"], ("y", "pre_d", "hidden", "buffer")):
+        assert torch.equal(a, b), what
+    yo, bo = oracle.delay_forward(res["fused"][1].cpu().numpy(), d, b0)
+    assert np.array_equal(res["fused"][0].cpu().numpy(), yo) and np.array_equal(res["fused"][3][:, 0].cpu().numpy(), bo)
+
+
 # ----------------------------------------------------------------------------- the loss leg inside the launch (round 3)
 @settings(max_examples=40, **SET)
 @given(B=st.sampled_from([1, 17, 1030, 1100, 2070]), T=st.integers(1, 900), skip4=st.integers(0, 230), odd=st.booleans(),
