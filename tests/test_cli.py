@@ -87,6 +87,31 @@ def test_parser_defaults_and_every_reference_flag():
         cli.resolve_weights("GRU-HS[64]-L[ESR]-DS[NoSuchDataset]_9", "../weights/")
 
 
+def test_parser_takes_the_other_evaluation_scripts():
+    """The command lines of scripts/test-model-prediction.sh:60-76, test-model-sweep.sh:56-62, test-model-hysteresis.sh:63-100 and
+    test-model-noise.sh with their shell variables substituted: all parse; the figure / noise flags land in the "ignored" set."""
+    cli = cli_module()
+    ds = "ReelToReel_Dataset_MiniPulse100_AKAI_IPS[7.5]_MAXELL"
+    prediction = ["--MODEL", "DiffDelGRU", "--WEIGHTS", W_D_AKAI, "--DATASET", ds, "--SEGMENT_LENGTH", "441000",
+                  "--SYNC", "0.0", "--NO_SHUFFLE", "--IDX", "3", "--ADD_DELAY", "--DELAY_TYPE", "Real", "--SAVE_AUDIO",
+                  "--DESCRIPTIVE_NAME", "PREDICTION_3_0_DELAY[Real]"]
+    noised = prediction[:-2] + ["--DATASET_NOISE", "Silence_AKAI_IPS[7.5]_MAXELL", "--ADD_NOISE", "--NOISE_TYPE", "Real",
+                                "--DESCRIPTIVE_NAME", "PREDICTION_3_0_DELAY[Real]_NOISE[Real]"]
+    sweep = ["--MODEL", "GRU", "--WEIGHTS", W_G_AKAI, "--DATASET", "SinesFadedShortContinuousPulse100_AKAI_IPS[7.5]_MAXELL",
+             "--SYNC", "5.0", "--SEGMENT_LENGTH", "441000", "--ZOOM", "10.0", "--NO_SHUFFLE", "--IDX", "0", "--DEMODULATE",
+             "--PLOT_SWEEP", "--SAVE_FIG", "--DESCRIPTIVE_NAME", "SWEEP_0"]
+    hysteresis = ["--MODEL", "DiffDelGRU", "--WEIGHTS", W_D_AKAI, W_D_WOW, "--DATASET", ds, "--SYNC", "0.0", "--SEGMENT_LENGTH", "44100",
+                  "--ZOOM", "0.1", "--NO_SHUFFLE", "--IDX", "7", "--DEMODULATE", "--PLOT_TRANSFER", "--SAVE_FIG", "--DESCRIPTIVE_NAME", "HYSTERESIS_7"]
+    for argv, ignored in ((prediction, []), (noised, ["ADD_NOISE"]), (sweep, ["SAVE_FIG", "PLOT_SWEEP", "ZOOM"]),
+                          (hysteresis, ["SAVE_FIG", "PLOT_TRANSFER", "ZOOM"])):
+        a = cli.parse_args(argv)
+        cli.check_model_flag(a.MODEL, a.WEIGHTS)
+        assert [k for k in cli.OUT_OF_SCOPE if getattr(a, k)] == ignored
+        assert a.SUBSET == "Val" and a.NO_SHUFFLE and not a.COMPUTE_LOSS and isinstance(a.IDX, int)
+    assert cli.parse_args(hysteresis).WEIGHTS == [W_D_AKAI, W_D_WOW]
+    assert cli.parse_args(sweep).SYNC == 5.0 and cli.parse_args(sweep).ZOOM == 10.0
+
+
 def test_weights_resolution_prefers_best_pth(tmp_path):
     """<MODEL_PATH>/<name>/best.pth (code/test-model.py:198-199,233) wins over the exported checkpoint of that name."""
     import torch

@@ -311,7 +311,10 @@ def example_prediction(a, feeder, models, init_len, say):
         else:
             assert d_traj is not None, "DiffDelGRU needs trajectory_<id>_*.npy side-cars"
             output, output_pre_d = model.predict(x_in, d_traj)
-            x_in, tgt, output = x_in[:, :, init_len:], tgt[:, :, init_len:], output[:, :, init_len:]     # :489-496
+            if not (a.PLOT_TRANSFER or a.PLOT_SWEEP):
+                x_in, tgt, output = x_in[:, :, init_len:], tgt[:, :, init_len:], output[:, :, init_len:]     # :486-496
+            else:
+                output = output_pre_d                 # :497-498: the transfer / sweep figures look at the nonlinearity alone
         if a.ADD_DELAY and a.MODEL == "GRU" and md['model_type'] == "GRU":
             assert d_traj is not None, "--ADD_DELAY needs delay trajectories (stereo dataset or side-cars)"
             output = ntm_amd.harness.apply_delay(md['delay'], d_traj, output, segment_length=2**12)       # :259-290
