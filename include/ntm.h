@@ -32,7 +32,7 @@ extern "C" {
 #define NTM_EHIP (-2)    /* HIP runtime error (launch failed, no device)               */
 #define NTM_EDELAY (-3)  /* reserved for host-side delay-range checks                  */
 
-#define NTM_ABI_VERSION 6 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag.  3: the TCN scratch is padded (ntm_tcn_scratch_floats grew), dilation / length limits.  4: ntm_diffdel_gru_forward is ONE fused launch where the matrix-pipe kernel runs (+ ntm_diffdel_gru_forward_ex).  5: ntm_gru_forward_esr, ntm_diffdel_gru_forward_esr.  6: ntm_tcn_forward works through the batch in stream chunks, ntm_tcn_scratch_floats is bounded (<= 2.0e9 floats + padding for any B), ntm_tcn_chunk_streams; DiffDelGRU warm-up calls always take the two-pass form */
+#define NTM_ABI_VERSION 7 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag.  3: the TCN scratch is padded (ntm_tcn_scratch_floats grew), dilation / length limits.  4: ntm_diffdel_gru_forward is ONE fused launch where the matrix-pipe kernel runs (+ ntm_diffdel_gru_forward_ex).  5: ntm_gru_forward_esr, ntm_diffdel_gru_forward_esr.  6: ntm_tcn_forward works through the batch in stream chunks, ntm_tcn_scratch_floats is bounded (<= 2.0e9 floats + padding for any B), ntm_tcn_chunk_streams; DiffDelGRU warm-up calls always take the two-pass form.  7: ntm_loss_scalars (+ include/ntm_rccl.h, libntm_rccl.so) */
 
 #define NTM_HIDDEN 64 /* hidden size of every shipped checkpoint (HS[64]): matrix-pipe and low-latency kernels.
                          H = 8, 16, 32 (the reference's constructor default is 8, code/model.py:22; its training
@@ -167,6 +167,16 @@ int ntm_diffdel_gru_forward_esr(const float *w_ih, const float *w_hh, const floa
 int ntm_esr_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int splits, double *out,
                  void *stream);
 int ntm_esr_splits(int64_t B, int64_t T, int64_t skip);
+
+/*
+ * This rank's four loss scalars from per-stream ESR rows (esr_out of ntm_gru_forward_esr / ntm_diffdel_gru_forward_esr, or the
+ * summed partial rows of ntm_esr_sums): what the loss loop of code/test-model.py:386-398 aggregates over the segments --
+ *     out4 = [ sum_b ESR_b,  B,  sum_b err2_b,  sum_b tgt2_b ],     ESR_b = (err2_b / n_samples) / (tgt2_b / n_samples + eps)
+ * (eps = 1e-5: CoreAudioML's ESRLoss; n_samples = T - skip) -- fp64, device in, device out, one small launch, bit-reproducible.
+ * A job sharded over ranks adds these four numbers over the ranks (ntm_rccl_allreduce_f64 in include/ntm_rccl.h, MPI, or
+ * torch.distributed) and divides out4[0] by out4[1]: the mean over segments of the per-segment loss.  B == 0 gives zeros.
+ */
+int ntm_loss_scalars(const double *esr_rows, int64_t B, int64_t n_samples, double eps, double *out4, void *stream);
 
 /*
  * As ntm_esr_sums, on the DC-blocked signals: both y and t pass H(z) = (1 - z^-1)/(1 - R z^-1) (zero state

@@ -46,6 +46,7 @@ _SIGNATURES = {
     "ntm_tcn_forward": (_int, [_vp, _int, _int, _int, ctypes.POINTER(_int), _vp, _vp, _i64, _i64, _vp, _vp]),
     "ntm_tcn_scratch_floats": (_i64, [_i64, _i64, _int]),
     "ntm_tcn_chunk_streams": (_i64, [_i64, _i64, _int]),
+    "ntm_loss_scalars": (_int, [_vp, _i64, _i64, ctypes.c_double, _vp, _vp]),
 }
 
 # include/ntm_lab.h: libntm_lab.so (older / experimental GRU kernels, diagnostic builds) -- tests and tools only
@@ -63,7 +64,7 @@ LAB_VARIANTS = ("mfma", "valu", "mfma3", "mfma4")
 
 _lib = None
 _lab = None
-ABI_VERSION = 6          # include/ntm.h NTM_ABI_VERSION this binding was written against
+ABI_VERSION = 7          # include/ntm.h NTM_ABI_VERSION this binding was written against
 HIDDEN_SIZES = (8, 16, 32, 64)
 NTM_DIFFDEL_AUTO, NTM_DIFFDEL_TWO_PASS, NTM_DIFFDEL_FUSED = 0, 1, 2
 DIFFDEL_MODES = {"auto": NTM_DIFFDEL_AUTO, "two_pass": NTM_DIFFDEL_TWO_PASS, "fused": NTM_DIFFDEL_FUSED}

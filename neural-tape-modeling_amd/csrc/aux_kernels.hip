@@ -203,6 +203,41 @@ __global__ __launch_bounds__(256) void esr_sums_kernel(const float *y, const flo
     }
 }
 
+// K3s: this rank's four loss scalars from its per-stream ESR rows -- what the loss loop of code/test-model.py:386-398
+// aggregates (sum over segments of the per-segment loss, segment count, and the raw sums): out4 = [sum_b ESR_b, B,
+// sum_b err2_b, sum_b tgt2_b] with ESR_b = (err2_b / n) / (tgt2_b / n + eps).  ONE workgroup, thread i adds rows i, i + 256, ...
+// in index order, fixed tree behind it: bit-reproducible, no atomics.  B rows of 16 bytes: nothing to optimise.
+__global__ __launch_bounds__(256) void loss_scalars_kernel(const double *rows, int64_t B, double n, double eps, double *out4)
+{
+    double se = 0.0, s0 = 0.0, s1 = 0.0;
+    for (int64_t b = threadIdx.x; b < B; b += 256) {
+        const double e = rows[2 * b], t = rows[2 * b + 1];
+        se += (e / n) / (t / n + eps);
+        s0 += e;
+        s1 += t;
+    }
+    __shared__ double red[3][256];
+    red[0][threadIdx.x] = se; red[1][threadIdx.x] = s0; red[2][threadIdx.x] = s1;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st)
+            for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out4[0] = red[0][0];
+        out4[1] = (double)B;
+        out4[2] = red[1][0];
+        out4[3] = red[2][0];
+    }
+}
+
+hipError_t launch_loss_scalars(const double *rows, int64_t B, double n, double eps, double *out4, hipStream_t stream)
+{
+    hipLaunchKernelGGL(loss_scalars_kernel, dim3(1), dim3(256), 0, stream, rows, B, n, eps, out4);
+    return hipGetLastError();
+}
+
 int esr_default_splits(int64_t B, int64_t T, int64_t skip)
 {
     const int64_t n = T - skip;

@@ -16,6 +16,7 @@ hipError_t launch_delay_update(const float *x, int64_t B, int64_t T, float *dl_s
 hipError_t launch_esr(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int splits, double *out,
                       hipStream_t stream);
 int esr_default_splits(int64_t B, int64_t T, int64_t skip);
+hipError_t launch_loss_scalars(const double *rows, int64_t B, double n, double eps, double *out4, hipStream_t stream);
 hipError_t launch_esr_dcpre(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, float R, double *out,
                             hipStream_t stream);
 hipError_t launch_stft_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, int n_fft, int hop,
@@ -302,6 +303,14 @@ int ntm_esr_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t s
     if (!y || !t || !out) return fail(NTM_EINVAL, "ntm_esr_sums: null pointer");
     hipError_t e = ntm::launch_esr(y, t, B, T, skip, splits, out, (hipStream_t)stream);
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_esr_sums");
+}
+
+int ntm_loss_scalars(const double *esr_rows, int64_t B, int64_t n_samples, double eps, double *out4, void *stream)
+{
+    if (B < 0 || n_samples <= 0 || !(eps >= 0.0)) return fail(NTM_EINVAL, "ntm_loss_scalars: bad size or eps");
+    if (!out4 || (B > 0 && !esr_rows)) return fail(NTM_EINVAL, "ntm_loss_scalars: null pointer");
+    hipError_t e = ntm::launch_loss_scalars(esr_rows, B, (double)n_samples, eps, out4, (hipStream_t)stream);
+    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_loss_scalars");
 }
 
 int ntm_esr_dcpre_sums(const float *y, const float *t, int64_t B, int64_t T, int64_t skip, float R, double *out,

@@ -493,3 +493,72 @@ def test_real_tape_command_line_at_the_operating_point(tmp_path, monkeypatch):
     assert "MultiSTFT" in got
     fsr, pred = wavfile.read(str(tmp_path / "results" / f"{ds}_LOSS_prediction_Supervised 2.wav"))
     assert fsr == fs and len(pred) == L - init and np.abs(pred.astype(np.float64) / 32767 - yo[2, init:]).max() < 1e-5 + 0.51 / 32767
+
+
+# ----------------------------------------------------------------------------- the one collective, without torch.distributed
+def test_loss_scalars_and_rccl_allreduce_through_ctypes(ntm):
+    """ntm_loss_scalars (this rank's four fp64 loss scalars from per-stream ESR rows, code/test-model.py:386-398) against numpy and
+    against distributed.local_loss_sums; then the SUM all-reduce of include/ntm_rccl.h on a communicator of one rank (the box has
+    one GPU): RCCL really initialises, reduces on the caller's stream and tears down; bit-reproducible from call to call."""
+    import ctypes
+    L = ntm._lib.lib()
+    R = ctypes.CDLL(os.path.join(os.path.dirname(ntm._lib.LIB_PATH), "libntm_rccl.so"))
+    R.ntm_rccl_last_error.restype = ctypes.c_char_p
+    rng = np.random.default_rng(12)
+    for B, n in ((1, 1000), (300, 64512), (5000, 441000 - 16384), (32768, 64512)):
+        rows = np.stack([rng.uniform(0.1, 5.0, B) * n * 1e-3, rng.uniform(0.5, 2.0, B) * n * 1e-2], 1)
+        dr = dev(rows)
+        out = torch.empty(4, dtype=torch.float64, device="cuda")
+        assert L.ntm_loss_scalars(ctypes.c_void_p(dr.data_ptr()), B, n, 1e-5, ctypes.c_void_p(out.data_ptr()), ntm._lib.current_stream()) == 0
+        got = out.cpu().numpy()
+        per = (rows[:, 0] / n) / (rows[:, 1] / n + 1e-5)
+        want = np.array([per.sum(), B, rows[:, 0].sum(), rows[:, 1].sum()])
+        assert np.abs(got / want - 1).max() < 1e-12
+        tl = ntm.distributed.local_loss_sums(dev(per), dr).cpu().numpy()
+        assert np.abs(got / tl - 1).max() < 1e-12
+        out2 = torch.empty_like(out)
+        L.ntm_loss_scalars(ctypes.c_void_p(dr.data_ptr()), B, n, 1e-5, ctypes.c_void_p(out2.data_ptr()), ntm._lib.current_stream())
+        assert torch.equal(out, out2)
+    zero = torch.full((4,), 7.0, dtype=torch.float64, device="cuda")
+    assert L.ntm_loss_scalars(None, 0, 10, 1e-5, ctypes.c_void_p(zero.data_ptr()), ntm._lib.current_stream()) == 0
+    assert zero.cpu().tolist() == [0.0, 0.0, 0.0, 0.0]
+    idb = (ctypes.c_ubyte * 128)()
+    comm = ctypes.c_void_p()
+    assert R.ntm_rccl_unique_id(idb) == 0, R.ntm_rccl_last_error()
+    assert R.ntm_rccl_comm_create(ctypes.byref(comm), 1, 0, idb) == 0, R.ntm_rccl_last_error()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        v = out.clone()
+        assert R.ntm_rccl_allreduce_f64(ctypes.c_void_p(v.data_ptr()), ctypes.c_int64(4), comm, ctypes.c_void_p(side.cuda_stream)) == 0, R.ntm_rccl_last_error()
+    side.synchronize()
+    assert torch.equal(v, out)                                   # one rank: the sum is the input
+    assert R.ntm_rccl_comm_destroy(comm) == 0
+
+
+def test_sharded_evaluation_from_a_plain_cpp_process(tmp_path):
+    """tools/cabi/cabi_demo `reduce` mode: what ONE rank of a torch-free multi-GPU evaluation runs -- ntm_gru_forward_esr (forward +
+    ESR sums in one call), ntm_loss_scalars, the RCCL all-reduce of the four scalars (a communicator of one rank here) -- against
+    the oracle: job ESR = mean over segments of the per-segment ESR (code/test-model.py:386-398)."""
+    import subprocess
+    import oracle
+    from helpers import oracle_weights
+    exe = os.path.join(ROOT, "tools", "cabi", "cabi_demo.bin")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-s", "-C", os.path.dirname(exe)], check=True)
+    W_G = "GRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE]_BEST"
+    rng = np.random.default_rng(31)
+    B, T, skip = 1045, 900, 64                      # 1045 > 1024: the matrix-pipe kernel, the sums ride in its launch
+    x = rng.uniform(-0.5, 0.5, (B, T)).astype(np.float32)
+    t = (0.4 * np.tanh(2 * x) + 0.01 * rng.standard_normal((B, T))).astype(np.float32)
+    x.tofile(str(tmp_path / "x.f32")); t.tofile(str(tmp_path / "t.f32"))
+    wfile = os.path.join(ROOT, "neural-tape-modeling_amd", "weights", "w0.bin")
+    r = subprocess.run([exe, "reduce", wfile, str(tmp_path / "x.f32"), str(tmp_path / "t.f32"), str(B), str(T), str(skip)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    vals = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in r.stdout.split() if "=" in kv}
+    yo, _ = oracle.gru_forward(oracle_weights(W_G), x, threads=4)               # h_0 = 0, as the demo passes it
+    so = oracle.esr_sums(yo, t, skip)
+    per = (so[:, 0] / (T - skip)) / (so[:, 1] / (T - skip) + 1e-5)
+    assert vals["ranks"] == 1 and vals["segments"] == B
+    assert abs(vals["sum_tgt2"] / so[:, 1].sum() - 1) < 1e-12 and abs(vals["sum_err2"] / so[:, 0].sum() - 1) < 1e-4
+    assert abs(vals["job_esr"] / per.mean() - 1) < 1e-4 and abs(vals["sum_esr"] / per.sum() - 1) < 1e-4

@@ -34,7 +34,35 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lab, s), f"libntm_lab.so does not export {s}"
         assert not hasattr(lib, s), f"the product library exports the laboratory symbol {s}"
     assert set(ntm_amd._lib._LAB_SIGNATURES) == set(lab_syms)
-    assert ntm_amd._lib.lib().ntm_abi_version() == 6 == ntm_amd._lib.ABI_VERSION
+    assert ntm_amd._lib.lib().ntm_abi_version() == 7 == ntm_amd._lib.ABI_VERSION
+
+
+def test_rccl_helper_library_loads_and_exports_its_header():
+    """include/ntm_rccl.h -> libntm_rccl.so (the one collective of the sharded path for torch-free callers): loads without a
+    GPU, exports every declared symbol, validates its arguments before RCCL is touched; libntm.so itself has no RCCL dependency."""
+    import subprocess
+    syms = header_symbols("ntm_rccl.h")
+    assert syms == ["ntm_rccl_allreduce_f64", "ntm_rccl_comm_create", "ntm_rccl_comm_destroy", "ntm_rccl_last_error", "ntm_rccl_unique_id"]
+    path = os.path.join(os.path.dirname(ntm_amd._lib.LIB_PATH), "libntm_rccl.so")
+    R = ctypes.CDLL(path)
+    for s in syms:
+        assert hasattr(R, s)
+    R.ntm_rccl_last_error.restype = ctypes.c_char_p
+    comm = ctypes.c_void_p()
+    idb = (ctypes.c_ubyte * 128)()
+    assert R.ntm_rccl_comm_create(None, 1, 0, idb) == -1 and b"null pointer" in R.ntm_rccl_last_error()
+    assert R.ntm_rccl_comm_create(ctypes.byref(comm), 2, 2, idb) == -1 and b"[0, nranks)" in R.ntm_rccl_last_error()
+    assert R.ntm_rccl_comm_create(ctypes.byref(comm), 0, 0, idb) == -1
+    assert R.ntm_rccl_allreduce_f64(None, ctypes.c_int64(0), None, None) == 0             # nothing to do
+    assert R.ntm_rccl_allreduce_f64(None, ctypes.c_int64(4), None, None) == -1
+    assert R.ntm_rccl_comm_destroy(None) == 0
+    needed = subprocess.run(["readelf", "-d", ntm_amd._lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in needed.lower()
+    # the four loss scalars: argument checks on the host
+    L = ntm_amd._lib.lib()
+    one = ctypes.c_void_p(16)
+    assert L.ntm_loss_scalars(one, 4, 0, 1e-5, one, None) == -1 and b"bad size" in L.ntm_last_error()
+    assert L.ntm_loss_scalars(None, 4, 10, 1e-5, one, None) == -1 and L.ntm_loss_scalars(one, 4, 10, 1e-5, None, None) == -1
 
 
 def test_cabi_pure_host_entry_points():

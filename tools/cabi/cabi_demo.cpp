@@ -6,6 +6,9 @@
 // pre_d (code/test-model.py:386-388):
 //   usage: cabi_demo diffdel <w2.bin> <x.f32> <d.f32> <B> <T> <D> <split> <out_prefix>
 //          writes <out_prefix>.y / .pre / .h / .buf (fp32), .esr (fp64 [B][2]), prints the flag values
+// and the sharded evaluation as a torch-free rank runs it -- forward + ESR sums in one call, this rank's four loss scalars, the
+// ONE collective of the path over RCCL (include/ntm_rccl.h; here a communicator of one rank: the box has one GPU):
+//   usage: cabi_demo reduce <w0.bin> <x.f32> <target.f32> <B> <T> <skip>      prints the four reduced scalars and the job ESR
 // w0.bin layout (neural-tape-modeling_amd/weights/manifest.json): W_ih[192] W_hh[192*64] b_ih[192] b_hh[192]
 // W_o[64] b_o[1], little-endian fp32 -- the reference's state_dict order (code/model.py:44-45).
 #include <hip/hip_runtime.h>
@@ -16,6 +19,7 @@
 #include <vector>
 
 #include "ntm.h"
+#include "ntm_rccl.h"
 
 static std::vector<float> read_f32(const char *path, size_t want)
 {
@@ -128,9 +132,50 @@ static int diffdel_main(int argc, char **argv)
     return 0;
 }
 
+static int reduce_main(int argc, char **argv)
+{
+    if (argc != 8) { fprintf(stderr, "usage: %s reduce w0.bin x.f32 target.f32 B T skip\n", argv[0]); return 1; }
+    const long B = atol(argv[5]), T = atol(argv[6]), skip = atol(argv[7]);
+    const size_t nw = 192 + 192 * 64 + 192 + 192 + 64 + 1;
+    std::vector<float> w = read_f32(argv[2], nw), x = read_f32(argv[3], (size_t)B * T), t = read_f32(argv[4], (size_t)B * T);
+    float *dw, *dx, *dt, *dy, *dh;
+    double *esr, *v4;
+    const size_t nb = (size_t)B * T * sizeof(float);
+    HIP_OK(hipMalloc(&dw, nw * sizeof(float)));
+    HIP_OK(hipMalloc(&dx, nb)); HIP_OK(hipMalloc(&dt, nb)); HIP_OK(hipMalloc(&dy, nb));
+    HIP_OK(hipMalloc(&dh, (size_t)B * 64 * sizeof(float)));
+    HIP_OK(hipMalloc(&esr, (size_t)B * 2 * sizeof(double)));
+    HIP_OK(hipMalloc(&v4, 4 * sizeof(double)));
+    HIP_OK(hipMemcpy(dw, w.data(), nw * sizeof(float), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dx, x.data(), nb, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dt, t.data(), nb, hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(dh, 0, (size_t)B * 64 * sizeof(float)));
+    hipStream_t stream;
+    HIP_OK(hipStreamCreate(&stream));
+    const float *w_ih = dw, *w_hh = dw + 192, *b_ih = w_hh + 192 * 64, *b_hh = b_ih + 192, *w_o = b_hh + 192, *b_o = w_o + 64;
+    // communicator: rank 0 makes the id; with more ranks the launcher would ship these 128 bytes to the others
+    unsigned char id[NTM_RCCL_ID_BYTES];
+    void *comm = nullptr;
+    if (ntm_rccl_unique_id(id) != 0 || ntm_rccl_comm_create(&comm, 1, 0, id) != 0) { fprintf(stderr, "rccl: %s\n", ntm_rccl_last_error()); return 10; }
+    if (ntm_rccl_comm_create(&comm, 2, 2, id) == 0) return 11;                    // rank out of range: refused before RCCL is called
+    if (ntm_gru_forward_esr(w_ih, w_hh, b_ih, b_hh, w_o, b_o, NTM_HIDDEN, dx, dy, B, T, T, T, dh, dt, skip, esr, stream) != NTM_OK) {
+        fprintf(stderr, "ntm_gru_forward_esr: %s\n", ntm_last_error()); return 7;
+    }
+    if (ntm_loss_scalars(esr, B, T - skip, 1e-5, v4, stream) != NTM_OK) { fprintf(stderr, "ntm_loss_scalars: %s\n", ntm_last_error()); return 12; }
+    if (ntm_loss_scalars(esr, B, 0, 1e-5, v4, stream) == NTM_OK) return 13;       // no samples: refused
+    if (ntm_rccl_allreduce_f64(v4, 4, comm, stream) != 0) { fprintf(stderr, "rccl: %s\n", ntm_rccl_last_error()); return 14; }
+    HIP_OK(hipStreamSynchronize(stream));
+    double h4[4];
+    HIP_OK(hipMemcpy(h4, v4, sizeof(h4), hipMemcpyDeviceToHost));
+    if (ntm_rccl_comm_destroy(comm) != 0) { fprintf(stderr, "rccl: %s\n", ntm_rccl_last_error()); return 15; }
+    printf("ok reduce ranks=1 sum_esr=%.17g segments=%.17g sum_err2=%.17g sum_tgt2=%.17g job_esr=%.17g\n", h4[0], h4[1], h4[2], h4[3], h4[0] / h4[1]);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc > 1 && std::string(argv[1]) == "diffdel") return diffdel_main(argc, argv);
+    if (argc > 1 && std::string(argv[1]) == "reduce") return reduce_main(argc, argv);
     if (argc != 7) { fprintf(stderr, "usage: %s w0.bin x.f32 B T y_out.f32 h_out.f32\n", argv[0]); return 1; }
     const long B = atol(argv[3]), T = atol(argv[4]);
     const size_t nw = 192 + 192 * 64 + 192 + 192 + 64 + 1;
