@@ -193,7 +193,12 @@ def measure_workload(workload, B, T, steps, warmup, check, dev, threads=1, delay
             ref = oracle.gru_predict(sd(weights.W_GRU), xs, threads=threads)[0]
     for _ in range(max(warmup, 1)):
         y0 = run()
-    y = run()          # one more untimed pass: the determinism target y0 stays alive, so the allocator needs one more block
+    # two more untimed passes: a timed pass allocates its output while the previous one is still alive, and the determinism
+    # target y0 stays alive too -- THREE output blocks must already sit in the caching allocator, or the first timed pass
+    # carries a hipMalloc of B x T x 4 bytes between its events (seen once: 8.6 GB took 245 ms on one box, gru_B32768 509 ms
+    # instead of 427)
+    y = run()
+    y = run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ms, k1, k2 = [], [], []
@@ -641,6 +646,13 @@ def main():
     if target is None:                      # --warmup 0: still need the first-pass output and the target
         y_first = one_pass(None)[0].clone()
         target = make_target(y_first)
+    # allocator pre-warm (untimed, whatever --warmup is): a timed step allocates its output and its sums while the previous
+    # step's are still alive; two passes with the loss leg put every such block into torch's caching allocator, so that no
+    # timed step carries a hipMalloc (with --warmup 1 the first timed step did)
+    for _ in range(2):
+        y, pend = one_pass(target)
+        torch.cuda.current_stream().wait_stream(side)
+        D.reduce_many([pend])
     if a.fail_rank == rank:                 # test hook: a rank that dies after warm-up, its peers left in the barrier
         torch.cuda.synchronize()
         os._exit(3)
@@ -789,6 +801,7 @@ def main():
                                + ("accumulated inside the recurrent launch" if fused_esr else "as a streaming pass on a side stream under the next step's launch")
                                + " + one all-reduce of the per-step loss scalars",
                    "segments_total": total_segments, "segments_rank0": B, "samples_per_segment": T, "kernel": a.variant,
+                   "untimed_passes_before_the_timed_region": max(a.warmup, 0) + (0 if a.warmup > 0 else 1) + 2,
                    "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
         "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if grouped else "none (single process)",
         "rccl_ranks": world if (backend == "nccl" and grouped) else 0, "ranks": world, "rank_devices": rank_devices,
