@@ -1,5 +1,5 @@
 """tools/test_model.py against the reference's command line (code/test-model.py:45-85): the argument vectors below are
-the ones scripts/test-model-loss.sh:57-73 (TOY) and :84-102 (REAL) issue, token for token."""
+the ones scripts/test-model-loss.sh:57-73 (TOY) and :87-113 (REAL) issue, token for token."""
 import importlib.util
 import os
 import sys
@@ -23,7 +23,7 @@ def cli_module(tag="ntm_cli_r4"):
 
 
 def loss_script_argv(model, weight, dataset, subset, mode):
-    """scripts/test-model-loss.sh:57-63 / :66-72 / :87-93 / :107-113 with the shell variables substituted."""
+    """scripts/test-model-loss.sh:57-63 / :67-73 / :87-93 / :107-113 with the shell variables substituted."""
     return ["--MODEL", model, "--WEIGHTS", weight,
             "--DATASET", dataset, "--SUBSET", subset, "--NO_SHUFFLE", "--SEGMENT_LENGTH", str(44100 * 10),
             mode,
