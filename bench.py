@@ -358,14 +358,16 @@ def live_traffic(kernel_regex, extra_args=()):
                 cmd = [prof, "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
                        os.path.abspath(__file__), "--steps", "5", "--warmup", "1", "--no-cpu-baseline", "--no-extra", "--other", "off",
                        "--traffic", "off"] + list(extra_args)
-                env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+                env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                                      "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "NTM_DIST_FORCE_INIT")
+                       and not k.startswith("TORCHELASTIC")}
                 env["TMPDIR"] = "/tmp"
                 # the profiler's python grandchild holds the GPU: on a timeout the whole process GROUP must go before the
                 # parent measures anything else (killing rocprofv3 alone would leave it launching 4096 x 65536 kernels)
                 proc = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
                                         start_new_session=True)
                 try:
-                    proc.communicate(timeout=120)
+                    proc.communicate(timeout=240)
                 except subprocess.TimeoutExpired:
                     import signal
                     try:
@@ -676,6 +678,15 @@ def main():
     # two rows that are equal on every rank may differ in the last bit after it), then combined over the ranks
     steps_identical = D.max_over_ranks(0.0 if all(torch.equal(p, pends[0]) for p in pends) else 1.0, dev) == 0.0
     kern_ms = [e0.elapsed_time(e1) for e0, e1 in step_evs]
+    # the per-GPU roofline is the SLOWEST rank's mean launch duration; the other ranks' means ride along for the record
+    kern_ms_rank = float(np.mean(kern_ms))
+    kmine = torch.tensor([kern_ms_rank, float(B)], dtype=torch.float64, device=dev)
+    if grouped:
+        kall = [torch.empty_like(kmine) for _ in range(world)]
+        torch.distributed.all_gather(kall, kmine)
+    else:
+        kall = [kmine]
+    kern_by_rank = [{"rank": r, "segments": int(v[1]), "kernel_ms": float(v[0])} for r, v in enumerate(kall)]
     sums_last = last["sums"].clone() if "sums" in last else None
     deterministic = bool(torch.equal(y, y_first))
 
@@ -750,7 +761,9 @@ def main():
     if rank != 0:
         return
     total_samples = float(total_segments) * T * a.steps
-    kern_s = float(np.mean(kern_ms)) / 1e3
+    # N > 1: the figure of the rank that bounds the job (largest launch duration per segment it owns), rank 0's when N = 1
+    slow = max(kern_by_rank, key=lambda d: d["kernel_ms"])
+    kern_s = kern_ms_rank / 1e3
     # exact-fp32 kernels: algorithmic flops against the fp32 matrix peak.  --variant f16x3 (opt-in): the MFMA
     # flops it actually executes (three fp16 products per W.h term) against the dense fp16 MFMA peak.
     flop_per_sample, peak_tflops, dtype = FLOP_PER_SAMPLE, PEAK_FP32_TFLOPS, "f32"
@@ -772,65 +785,108 @@ def main():
         checks["stream0_vs_reference_esr"] = float((e[INIT_LEN:] ** 2).mean() /
                                                    ((gold["y"][0, 0][INIT_LEN:] ** 2).mean() + ESR_EPS))
     # HBM bytes per launch from the PMC counters, collected as MI355X_MICROARCH.md prescribes (separate rocprofv3 --pmc
-    # passes, gfx950 FETCH_SIZE correction) -- only for the matching workload.  `--traffic live` (what `auto` does when
-    # rocprofv3 is on the PATH): the two passes run NOW, as child processes of this line's own command at 2 steps, so the
-    # number belongs to this box and this binary; otherwise, or if a pass fails, the newest profiles/*pmc_traffic*.json.
+    # passes, gfx950 FETCH_SIZE correction), for the launch THIS rank timed (B streams x T samples).  `--traffic live` (what
+    # `auto` does when rocprofv3 is on the PATH): the two passes run NOW, as single-GPU child processes of this line's own
+    # command at this rank's batch and 5 steps (N > 1: after the process group is gone, on rank 0's GPU -- the launch of a
+    # rank does not depend on N), so the number belongs to this box and this binary; otherwise, or if a pass fails, the
+    # newest profiles/*pmc_traffic* file of the same kernel and shape.
     traffic, traffic_source = None, None
-    if (B, T) == (4096, 65536) and a.variant in ("auto", "mfma2") and a.traffic != "off":
+    many = (B + 15) // 16 > torch.cuda.get_device_properties(local).multi_processor_count      # launch_gru_mfma2: YPN 4 / 16
+    if T == 65536 and B > 1024 and a.variant in ("auto", "mfma2") and a.traffic != "off":
         profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
-        rx = r"gru_mfma2_kernel<true, false, 0, 0, 16, false, " + ("true>" if fused_esr else "false>")
-        if a.traffic == "live" or (a.traffic == "auto" and world == 1 and not profiled):     # never a profiler inside a profiler
-            traffic, traffic_source = live_traffic(rx, ["--esr", a.esr, "--variant", a.variant, "--batch", str(a.batch),
+        rx = r"gru_mfma2_kernel<true, false, 0, 0, " + ("4" if many else "16") + ", false, " + ("true>" if fused_esr else "false>")
+        if a.traffic == "live" or (a.traffic == "auto" and not profiled):     # never a profiler inside a profiler
+            traffic, traffic_source = live_traffic(rx, ["--esr", a.esr, "--variant", a.variant, "--batch", str(B),
                                                         "--samples", str(a.samples)])
         if traffic is None:
             import glob
-            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic_mfma2_esr*.json" if fused_esr else "*pmc_traffic_mfma2.json")))
+            tag = "" if B == 4096 else f"_B{B}"
+            pats = [f"*pmc_traffic_mfma2_esr{tag}.json"] if fused_esr else [f"*pmc_traffic_mfma2{tag}.json", f"*pmc_traffic_gru_B{B}.json"]
+            files = sorted(f for pat in pats for f in glob.glob(os.path.join(ROOT, "profiles", pat)))
             if files:
                 why = f"; live passes: {traffic_source}" if traffic_source else ""
                 traffic = json.load(open(files[-1]))["hbm_bytes_per_launch_corrected"]
-                traffic_source = ("profiles/" + os.path.basename(files[-1]) + " (rocprofv3 --pmc passes of this command; not "
-                                  "re-measured in this run" + why + ")")
+                traffic_source = ("profiles/" + os.path.basename(files[-1]) + " (rocprofv3 --pmc passes of this rank's launch as a "
+                                  "single-GPU command; not re-measured in this run" + why + ")")
+    # roofline of the dominant launch: the per-GPU figure (this rank's launch: B streams) and, for N > 1, the job's --
+    # all ranks' algorithmic flops over the SLOWEST rank's mean launch duration, against N x the peak
+    roofline = {"bound": "mfma", "achieved": tflops, "peak": peak_tflops, "unit": "TFLOP/s",
+                "frac": tflops / peak_tflops, "traffic": traffic, "traffic_source": traffic_source,
+                "algorithmic_bytes": float(bytes_per_sample) * B * T,
+                "kernel": {"auto": "gru_mfma2_kernel", "mfma2": "gru_mfma2_kernel", "mfma": "gru_mfma_kernel",
+                           "valu": "gru_valu_kernel", "f16x3": "gru_mfma2_kernel<f16x3>", "mfma4": "gru_mfma4_kernel"}[a.variant]
+                          + ("<ESR: forward + loss sums>" if fused_esr else ""),
+                "kernel_ms": 1e3 * kern_s, "flop_per_sample": flop_per_sample, "per": "GPU (rank 0's launch)",
+                "segments_in_launch": B,
+                "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": hbm_gbs / PEAK_HBM_GBS, "bytes_per_sample": bytes_per_sample,
+                        "copy_kernel_measured": hbm_copy_gbs}}
+    agg_tflops = flop_per_sample * float(total_segments) * T / (slow["kernel_ms"] * 1e-3) / 1e12
+    roofline["aggregate"] = {"n_gpus": world, "achieved": agg_tflops, "peak": world * peak_tflops, "unit": "TFLOP/s",
+                             "frac": agg_tflops / (world * peak_tflops),
+                             "what": "all ranks' algorithmic flops / the slowest rank's mean launch duration, against N x the per-GPU peak",
+                             "slowest_rank": slow["rank"], "kernel_ms_by_rank": kern_by_rank,
+                             "hbm": {"achieved": bytes_per_sample * float(total_segments) * T / (slow["kernel_ms"] * 1e-3) / 1e9,
+                                     "peak": world * PEAK_HBM_GBS, "unit": "GB/s",
+                                     "frac": bytes_per_sample * float(total_segments) * T / (slow["kernel_ms"] * 1e-3) / 1e9 / (world * PEAK_HBM_GBS)}}
+    per_gpu = f"{B}/GPU" if a.scaling == "weak" else f"{a.total_batch} total, {B} on rank 0"
     out = {
-        "metric": "audio samples/sec (44.1 kHz) GRU-HS[64], batch=4096x65536",
+        # BASELINE.json's metric with the point of its "1/2/4/8 GPU" axis this line is
+        "metric": f"audio samples/sec (44.1 kHz) GRU-HS[64], batch={a.batch if a.scaling == 'weak' else B}x{T}"
+                  + (f", {world} GPU" if world == 1 and a.scaling == "weak" else f" per GPU, {world} GPU ({a.scaling} scaling, {total_segments} segments)"),
         "value": total_samples / elapsed, "unit": "samples/s", "n_gpus": world, "steps": a.steps,
-        "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "ms_per_step_no_warm_cache": ms_no_cache, "higher_is_better": True,
+        "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "ms_per_step_no_warm_cache": ms_no_cache,
+        "value_no_warm_cache": float(total_segments) * T / (ms_no_cache * 1e-3), "higher_is_better": True,
         "scaling": a.scaling, "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-        "config": {"workload": f"GRU-HS[64] CHOWTAPE weights, {total_segments} segments x {T} samples fp32 "
-                               f"({B} on rank 0), "
-                               f"predict (warm-start state, kept per parameter version after the first pass, + persistent GRU kernel) + ESR sums "
-                               + ("accumulated inside the recurrent launch" if fused_esr else "as a streaming pass on a side stream under the next step's launch")
-                               + " + one all-reduce of the per-step loss scalars",
+        # (the driver keeps 120 characters of this string)
+        "config": {"workload": f"GRU-HS[64] {total_segments}x{T} f32 on {world} GPU ({per_gpu}), predict+ESR "
+                               + ("fused" if fused_esr else "as a side-stream pass") + ", warm-cache on, 1 all-reduce/job",
+                   "workload_detail": "CHOWTAPE weights; a step = RNN.predict over the rank's resident batch (warm-start state of 1024 zero samples kept "
+                                      "per parameter version after the first pass, then ONE persistent GRU launch) with the per-stream ESR sums "
+                                      + ("accumulated inside the recurrent launch" if fused_esr else "as a streaming pass on a side stream under the next step's launch")
+                                      + "; the K steps' loss scalars go through one all-reduce before the closing synchronisation; "
+                                        "value_no_warm_cache = the same step with the warm-start launch recomputed every pass (code/model.py:229-230)",
                    "segments_total": total_segments, "segments_rank0": B, "samples_per_segment": T, "kernel": a.variant,
                    "untimed_passes_before_the_timed_region": max(a.warmup, 0) + (0 if a.warmup > 0 else 1) + 2,
                    "parallelism": f"streams sharded over {world} GPU(s), no data-path collective"},
         "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if grouped else "none (single process)",
         "rccl_ranks": world if (backend == "nccl" and grouped) else 0, "ranks": world, "rank_devices": rank_devices,
         "realtime_factor": total_samples / elapsed / FS,
-        "roofline": {"bound": "mfma", "achieved": tflops, "peak": peak_tflops, "unit": "TFLOP/s",
-                     "frac": tflops / peak_tflops, "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": {"auto": "gru_mfma2_kernel", "mfma2": "gru_mfma2_kernel", "mfma": "gru_mfma_kernel",
-                                "valu": "gru_valu_kernel", "f16x3": "gru_mfma2_kernel<f16x3>", "mfma4": "gru_mfma4_kernel"}[a.variant]
-                               + ("<ESR: forward + loss sums>" if fused_esr else ""),
-                     "kernel_ms": 1e3 * kern_s, "flop_per_sample": flop_per_sample,
-                     "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": hbm_gbs / PEAK_HBM_GBS, "bytes_per_sample": bytes_per_sample,
-                             "copy_kernel_measured": hbm_copy_gbs}},
+        "roofline": roofline,
         "checks": checks,
     }
+    info = os.path.join(ROOT, "neural-tape-modeling_amd", "build_info.json")      # written by __graft_entry__.build()
+    bi = None
+    try:
+        if os.path.exists(info) and os.path.getmtime(info) >= os.path.getmtime(ntm_amd._lib.LIB_PATH):
+            bi = json.load(open(info))
+        else:                                     # no record of THIS library: read its code objects now
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import kernel_resources
+            bi = kernel_resources.build_info(ntm_amd._lib.LIB_PATH)
+    except Exception as e:                        # the record is a courtesy: never at the cost of the line
+        out["build"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    if bi is not None:
+        want = roofline["kernel"].split("<")[0]
+        out["build"] = {"compiler": bi.get("compiler"), "arch": bi.get("arch"), "git_head_at_build": bi.get("git_head_at_build"),
+                        "runtime_hip": torch.version.hip,
+                        "kernels": [{k: v for k, v in kk.items() if k != "symbol"} for kk in bi.get("kernels", [])
+                                    if want in kk["kernel"] or "gru_lat_kernel" in kk["kernel"]]}
     if extra:
         out["other_kernels"] = extra
-    if world == 1 and not a.no_cpu_baseline:
+    if not a.no_cpu_baseline:
+        # N > 1: rank 0 alone, after the process group is gone (the other ranks have left; nothing of this is timed)
         out["cpu_baseline"] = cpu_baseline(weights.W_GRU)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        # CPU leg, outside the timed region: scattered streams of the LAST timed step's output against the C oracle over
-        # the whole sequence (the oracle is the checker here, never the thing measured)
+        # CPU leg, outside the timed region: scattered streams of the LAST timed step's output (rank 0's rows) against the C
+        # oracle over the whole sequence (the oracle is the checker here, never the thing measured)
         import oracle
         rows = sorted({r for r in (1, 15, 16, 17, B // 2 - 1, B // 2, B - 2, B - 1) if 0 <= r < B})
         w_or = oracle.Weights.from_state_dict({k: v.numpy() for k, v in weights.load_state_dict(weights.W_GRU).items()})
         yo, _ = oracle.gru_predict(w_or, x[rows, 0].cpu().numpy(), threads=out["cpu_baseline"]["cores"])
         yr, tr = y[rows, 0].cpu().numpy(), target[rows, 0].cpu().numpy()
-        out["checks"]["streams_vs_oracle"] = {"rows": rows, "samples_each": T,
-                                              "max_abs": float(np.abs(yr - yo).max()), "tolerance": 1e-5}
+        out["checks"]["streams_vs_oracle"] = {"rows": rows, "rows_of": f"rank 0 (segments {first_segment} .. {first_segment + B - 1} of the job)",
+                                              "samples_each": T, "max_abs": float(np.abs(yr - yo).max()), "tolerance": 1e-5}
         if sums_last is not None:
             # the loss leg of the LAST timed step: the sums that rode in the recurrent launch against the oracle's esr_sums of
             # the same rows (same y, same target: the accumulation is what is checked, rel 1e-9), and the per-stream ESR the

@@ -35,9 +35,13 @@ extern "C" {
 #define NTM_ABI_VERSION 7 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag.  3: the TCN scratch is padded (ntm_tcn_scratch_floats grew), dilation / length limits.  4: ntm_diffdel_gru_forward is ONE fused launch where the matrix-pipe kernel runs (+ ntm_diffdel_gru_forward_ex).  5: ntm_gru_forward_esr, ntm_diffdel_gru_forward_esr.  6: ntm_tcn_forward works through the batch in stream chunks, ntm_tcn_scratch_floats is bounded (<= 2.0e9 floats + padding for any B), ntm_tcn_chunk_streams; DiffDelGRU warm-up calls always take the two-pass form.  7: ntm_loss_scalars (+ include/ntm_rccl.h, libntm_rccl.so) */
 
 #define NTM_HIDDEN 64 /* hidden size of every shipped checkpoint (HS[64]): matrix-pipe and low-latency kernels.
-                         H = 8, 16, 32 (the reference's constructor default is 8, code/model.py:22; its training
-                         default 16, code/train.py:50) run on one wave-per-64/H-streams kernel, any variant
-                         among AUTO / LAT / VALU.                                                               */
+                         Every other H in [1, NTM_MAX_HIDDEN] (the reference's `--HIDDEN_SIZE` is a free integer,
+                         code/train.py:50; its constructor default is 8, code/model.py:22, its training default 16)
+                         runs on gru_small.hip, any variant among AUTO / LAT / VALU: H = 8, 16, 32 one wavefront per
+                         64/H streams; other H < 64 the same kernel zero-padded to the next power of two; 64 < H <=
+                         128 a workgroup per stream with the weights in registers; above that a plain kernel that
+                         streams the weights from L2 (correct, not fast).                                          */
+#define NTM_MAX_HIDDEN 1024
 
 /* GRU kernel variants.  ntm_gru_forward_ex of libntm.so (the product) accepts NTM_GRU_AUTO, _MFMA2,
  * _LAT and the opt-in _F16X3; the others are LABORATORY kernels -- older or experimental exact-fp32 implementations
@@ -69,7 +73,7 @@ const char *ntm_last_error(void);
  *   b_ih [3H]      GRU.bias_ih_l0               b_hh [3H]     GRU.bias_hh_l0
  *   w_o  [H]       output.weight (1,H)          b_o  [1] or NULL   output.bias
  * x [B,T] (stride x_stride_b) -> y [B,T] (stride y_stride_b).
- * H in {8, 16, 32, 64}.  h_state [B,H] is read as h_0 and overwritten with h_T (the reference's self.hidden);
+ * 1 <= H <= NTM_MAX_HIDDEN.  h_state [B,H] is read as h_0 and overwritten with h_T (the reference's self.hidden);
  * NULL means h_0 = 0 and h_T is discarded.  B == 0 or T == 0 is a successful no-op.
  */
 int ntm_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
@@ -290,9 +294,10 @@ int ntm_fir_f64(const double *x, double *y, int64_t B, int64_t N, const double *
  * function).  A batch whose activations exceed 8 GB is worked through in chunks of ntm_tcn_chunk_streams(B,T,C) streams
  * (streams are independent; same results bit for bit): the scratch never exceeds 2e9 floats (+ padding) whatever B is --
  * 8 GB for 32 768 x 65 536 instead of 2 x 275 GB.  Chunks alternate between two lanes, each with its own pair of
- * activation buffers inside `scratch` and its own HIP stream, forked from and joined to `stream` by events (created and
- * destroyed inside the call): the call is ordered on `stream` like any other, nothing outlives it, and one chunk's drain
- * and HBM-bound first block run under the other chunk's matrix-pipe blocks.  Limits: T < 2^31 - 2^25,
+ * activation buffers inside `scratch` and its own HIP stream, forked from and joined to `stream` by events (the two side
+ * streams and three events are created on the first chunked call on a device and kept -- the library's only state, it
+ * holds no data): the call returns as soon as the work is enqueued, is ordered on `stream` like any other, and one
+ * chunk's drain and HBM-bound first block run under the other chunk's matrix-pipe blocks.  Limits: T < 2^31 - 2^25,
  * 1 <= dil[l] <= 2^20 (NTM_EINVAL otherwise).
  */
 int ntm_tcn_forward(const float *params, int L, int C, int K, const int *dil, const float *x,

@@ -65,7 +65,8 @@ LAB_VARIANTS = ("mfma", "valu", "mfma3", "mfma4")
 _lib = None
 _lab = None
 ABI_VERSION = 7          # include/ntm.h NTM_ABI_VERSION this binding was written against
-HIDDEN_SIZES = (8, 16, 32, 64)
+HIDDEN_SIZES = (8, 16, 32, 64)      # sizes with a kernel of their own; every H in [1, MAX_HIDDEN] runs (include/ntm.h)
+MAX_HIDDEN = 1024
 NTM_DIFFDEL_AUTO, NTM_DIFFDEL_TWO_PASS, NTM_DIFFDEL_FUSED = 0, 1, 2
 DIFFDEL_MODES = {"auto": NTM_DIFFDEL_AUTO, "two_pass": NTM_DIFFDEL_TWO_PASS, "fused": NTM_DIFFDEL_FUSED}
 

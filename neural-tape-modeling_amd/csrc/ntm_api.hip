@@ -1,9 +1,10 @@
 // extern "C" surface of libntm.so (declared in include/ntm.h): argument checking, variant choice,
 // error reporting.  No allocation, no synchronisation, no global mutable state besides the
-// thread-local error string.
+// thread-local error string and the per-device pool of two side streams ntm_tcn_forward keeps for chunked batches.
 #include "ntm.h"
 #include "ntm_common.h"
 
+#include <mutex>
 #include <string>
 
 namespace ntm {
@@ -59,17 +60,18 @@ int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, 
                        const float *b_o, int H, const float *x, float *y, int64_t B, int64_t T, int64_t x_stride_b,
                        int64_t y_stride_b, float *h_state, int variant, void *stream)
 {
-    if (H != 8 && H != 16 && H != 32 && H != NTM_HIDDEN)
-        return fail(NTM_EINVAL, "ntm_gru_forward: hidden sizes 8, 16, 32 and 64 are compiled");
+    if (H < 1 || H > NTM_MAX_HIDDEN) return fail(NTM_EINVAL, "ntm_gru_forward: hidden size must lie in [1, 1024]");
     if (B < 0 || T < 0) return fail(NTM_EINVAL, "ntm_gru_forward: negative B or T");
     if (B == 0 || T == 0) return NTM_OK;
     if (!w_ih || !w_hh || !b_ih || !b_hh || !w_o || !x || !y) return fail(NTM_EINVAL, "ntm_gru_forward: null pointer");
     if (x_stride_b < T || y_stride_b < T) return fail(NTM_EINVAL, "ntm_gru_forward: stride < T");
     if (H != NTM_HIDDEN) {
-        // small hidden sizes (the reference's constructor / training defaults, code/model.py:22, code/train.py:50):
-        // one kernel, 64/H streams per wavefront; the matrix-pipe variants exist for H = 64 only
+        // every other hidden size (the reference's constructor / training defaults 8 and 16, code/model.py:22,
+        // code/train.py:50, and whatever --HIDDEN_SIZE a user trained with): gru_small.hip -- 64/HP streams per wavefront at
+        // the next power of two HP for H < 64, a workgroup per stream above; the matrix-pipe variants exist for H = 64 only
         if (variant != NTM_GRU_AUTO && variant != NTM_GRU_LAT && variant != NTM_GRU_VALU)
             return fail(NTM_EINVAL, "ntm_gru_forward: the matrix-pipe kernel variants are compiled for hidden size 64 only");
+        if (H > NTM_HIDDEN && B > 0x7fffffff) return fail(NTM_EINVAL, "ntm_gru_forward: at most 2^31 - 1 streams per call for H > 64");
         ntm::GruArgs as{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, x_stride_b, y_stride_b, nullptr, 0, 0};
         hipError_t es = ntm::launch_gru_small(as, H, (hipStream_t)stream);
         return es == hipSuccess ? NTM_OK : hip_fail(es, "ntm_gru_forward");
@@ -114,8 +116,7 @@ int ntm_gru_forward_esr(const float *w_ih, const float *w_hh, const float *b_ih,
                         int64_t y_stride_b, float *h_state, const float *target, int64_t skip, double *esr_out, void *stream)
 {
     // every argument is checked BEFORE anything is enqueued: an NTM_EINVAL leaves y, h_state and esr_out untouched
-    if (H != 8 && H != 16 && H != 32 && H != NTM_HIDDEN)
-        return fail(NTM_EINVAL, "ntm_gru_forward_esr: hidden sizes 8, 16, 32 and 64 are compiled");
+    if (H < 1 || H > NTM_MAX_HIDDEN) return fail(NTM_EINVAL, "ntm_gru_forward_esr: hidden size must lie in [1, 1024]");
     if (B < 0 || T < 0 || skip < 0 || skip > T) return fail(NTM_EINVAL, "ntm_gru_forward_esr: bad size");
     if (B == 0) return NTM_OK;
     if (!target || !esr_out) return fail(NTM_EINVAL, "ntm_gru_forward_esr: null pointer");
@@ -181,17 +182,19 @@ static int diffdel_impl(const float *w_ih, const float *w_hh, const float *b_ih,
     // target != NULL: also the per-stream ESR sums of y against target over [skip, T) (ntm_diffdel_gru_forward_esr): inside the
     // fused launch where it runs and skip is a multiple of 4, by the streaming pass (one row per stream) everywhere else
     const bool esr_in_kernel = target && (skip & 3) == 0 && !warmup;
+    // every argument is checked BEFORE anything is enqueued: an NTM_EINVAL leaves y, pre_d, the states and esr_out untouched
     if (B < 0 || T < 0 || D < 0) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: negative size");
+    if (H < 1 || H > NTM_MAX_HIDDEN) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: hidden size must lie in [1, 1024]");
     if (B == 0) return NTM_OK;
-    if (target && T == 0) {            // no samples: the sums are zero
-        hipError_t ez = hipMemsetAsync(esr_out, 0, (size_t)B * 2 * sizeof(double), (hipStream_t)stream);
-        if (ez != hipSuccess) return hip_fail(ez, "ntm_diffdel_gru_forward_esr");
-    }
     if (!pre_d || pre_d == y) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: pre_d must be a distinct buffer");
     if (mode != NTM_DIFFDEL_AUTO && mode != NTM_DIFFDEL_TWO_PASS && mode != NTM_DIFFDEL_FUSED)
         return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: unknown mode");
     if (mode == NTM_DIFFDEL_FUSED && H != NTM_HIDDEN)
         return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: the fused kernel is compiled for hidden size 64 only");
+    if (target && T == 0) {            // no samples: the sums are zero
+        hipError_t ez = hipMemsetAsync(esr_out, 0, (size_t)B * 2 * sizeof(double), (hipStream_t)stream);
+        return ez == hipSuccess ? NTM_OK : hip_fail(ez, "ntm_diffdel_gru_forward_esr");
+    }
     // how many streams take the fused matrix-pipe kernel: all of them when forced; under AUTO the streams
     // ntm_gru_forward would give to that kernel (B > NTM_GRU_LAT_MAX_B; a remainder of at most that many streams behind
     // whole device rounds goes to the low-latency kernel + the streaming delay pass, as there)
@@ -436,13 +439,25 @@ int ntm_fir_f64(const double *x, double *y, int64_t B, int64_t N, const double *
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_fir_f64");
 }
 
+namespace {
+constexpr int kMaxDevices = 64;
+struct TcnLanes {
+    std::mutex mu;
+    bool ready = false;
+    hipStream_t lane[2] = {nullptr, nullptr};
+    hipEvent_t fork = nullptr, done[2] = {nullptr, nullptr};
+};
+TcnLanes g_tcn_lanes[kMaxDevices];      // never destroyed: the runtime may already be gone when statics are torn down
+}  // namespace
+
 // The batch is processed in chunks of streams (streams are independent): the scratch is bounded by TCN_SCRATCH_BUDGET floats
 // whatever B is -- 4096 x 65 536 x 32 ch took two 34.4 GB buffers as one launch set, and the per-GPU shapes of BASELINE
 // configs[4] (B >= 8192) did not fit at all.  A batch that needs more than one chunk runs on TWO lanes: chunk k goes to lane
 // k & 1, each lane has its own pair of activation buffers and its own HIP stream (forked from / joined to the caller's
-// stream by events, created and destroyed inside the call), so the drain of one chunk's launch is filled by the other
+// stream by events), so the drain of one chunk's launch is filled by the other
 // lane's launch and the HBM-bound first block of one chunk runs under the matrix-pipe blocks of the other.  Chunks are
-// equal-sized (the last may be smaller).
+// equal-sized (the last may be smaller).  (The lane streams / events live in a per-device pool: this is the library's only
+// state besides the thread-local error string, and it holds no data.)
 static const int64_t TCN_SCRATCH_BUDGET = 2000000000;      // floats in total (8 GB): 2 lanes x 2 activation buffers
 static int64_t tcn_chunk_streams(int64_t B, int64_t T, int C)
 {
@@ -486,31 +501,37 @@ int ntm_tcn_forward(const float *params, int L, int C, int K, const int *dil, co
         hipError_t e = ntm::launch_tcn(params, L, C, K, dil, x, y, B, T, scratch, user);
         return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_tcn_forward");
     }
-    // two lanes; everything created here is released before returning (destroying a stream / event with work pending
-    // is legal: the runtime frees it when that work has completed)
+    // two lanes: the side streams and the three events are created once per device and kept for the life of the process
+    // (round 4 created and destroyed them per call -- hipStreamDestroy may wait for the queue to drain, which would have
+    // turned "asynchronous on `stream`" into a host-blocking call for every chunked batch, and stream creation cannot be
+    // captured into a graph).  The pool's mutex is held while the call ENQUEUES (microseconds): calls on one device share
+    // the lanes, which only serialises work that would contend for the same CUs anyway.
     const int64_t lane_floats = 2 * (bc * T * (int64_t)C + 16 * (int64_t)C);
-    hipStream_t lane[2] = {nullptr, nullptr};
-    hipEvent_t fork = nullptr, done[2] = {nullptr, nullptr};
-    hipError_t e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-        e = hipStreamCreateWithFlags(&lane[i], hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+    int devi = 0;
+    hipError_t e = hipGetDevice(&devi);
+    if (e != hipSuccess) return hip_fail(e, "ntm_tcn_forward");
+    if (devi < 0 || devi >= kMaxDevices) return fail(NTM_EINVAL, "ntm_tcn_forward: device ordinal beyond the lane pool");
+    TcnLanes &P = g_tcn_lanes[devi];
+    std::lock_guard<std::mutex> hold(P.mu);
+    if (!P.ready) {
+        e = hipEventCreateWithFlags(&P.fork, hipEventDisableTiming);
+        for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+            e = hipStreamCreateWithFlags(&P.lane[i], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&P.done[i], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) return hip_fail(e, "ntm_tcn_forward");       // (a half-built pool is retried by the next call)
+        P.ready = true;
     }
-    if (e == hipSuccess) e = hipEventRecord(fork, user);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamWaitEvent(lane[i], fork, 0);
+    e = hipEventRecord(P.fork, user);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipStreamWaitEvent(P.lane[i], P.fork, 0);
     int k = 0;
     for (int64_t b0 = 0; b0 < B && e == hipSuccess; b0 += bc, ++k) {
         const int64_t n = B - b0 < bc ? B - b0 : bc;
-        e = ntm::launch_tcn(params, L, C, K, dil, x + b0 * T, y + b0 * T, n, T, scratch + (k & 1) * lane_floats, lane[k & 1]);
+        e = ntm::launch_tcn(params, L, C, K, dil, x + b0 * T, y + b0 * T, n, T, scratch + (k & 1) * lane_floats, P.lane[k & 1]);
     }
     for (int i = 0; i < 2; ++i) {              // join -- also after an error, so that nothing outlives the caller's ordering
-        if (lane[i] && done[i] && hipEventRecord(done[i], lane[i]) == hipSuccess) (void)hipStreamWaitEvent(user, done[i], 0);
+        if (hipEventRecord(P.done[i], P.lane[i]) == hipSuccess) (void)hipStreamWaitEvent(user, P.done[i], 0);
     }
-    for (int i = 0; i < 2; ++i) {
-        if (done[i]) (void)hipEventDestroy(done[i]);
-        if (lane[i]) (void)hipStreamDestroy(lane[i]);
-    }
-    if (fork) (void)hipEventDestroy(fork);
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_tcn_forward");
 }
 

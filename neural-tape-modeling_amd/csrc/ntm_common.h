@@ -45,6 +45,8 @@ struct GruArgs {
     const float *tgt = nullptr;     // target [B,T], contiguous
     double *esr_out = nullptr;      // [B,2] fp64
     int64_t esr_skip = 0;           // multiple of 4
+    int H = 64;                     // hidden size as the caller's tensors have it (gru_small.hip: any size but 64; the
+                                    // matrix-pipe / low-latency kernels are compiled for kH)
 };
 
 }  // namespace ntm
@@ -67,6 +69,6 @@ hipError_t launch_gru_mfma2_fused(const GruArgs &a, hipStream_t stream);   // GR
 hipError_t launch_gru_mfma3(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_lat(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_mfma4(const GruArgs &a, hipStream_t stream);
-hipError_t launch_gru_small(const GruArgs &a, int H, hipStream_t stream);   // H = 8, 16, 32
+hipError_t launch_gru_small(const GruArgs &a, int H, hipStream_t stream);   // any H in [1, 1024] but 64
 hipError_t launch_debug_transpose(const float *in, float *out, hipStream_t stream);
 }  // namespace ntm

@@ -1,0 +1,227 @@
+"""Round 5: ANY hidden size (the reference's `--HIDDEN_SIZE` is a free integer, code/train.py:50, code/model.py:22,44-45) against
+goldens made by the reference itself (g21, tools/make_goldens_anyh.py) and the oracle; the evaluation CLI's loss cache
+(tools/test_model.py) with directory-path weights and changed arguments; the DCPreESR sums out of the recurrent launch."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import ROOT, load
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5          # north_star: |hip - PyTorch-CPU fp32| < 1e-5
+
+
+@pytest.fixture(scope="module")
+def ntm():
+    import ntm_amd
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    ntm_amd._lib.lib()
+    return ntm_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _from_golden(ntm, g, prefix, H, cls, **kw):
+    m = cls(1, H, 1, **kw)
+    m.load_state_dict({k[len(prefix):]: torch.from_numpy(g[k]) for k in g.files if k.startswith(prefix)})   # reference format, strict
+    return m.to("cuda").eval()
+
+
+# ----------------------------------------------------------------------------- any hidden size
+@pytest.mark.parametrize("H", [5, 24, 48, 96, 200])
+def test_g21_any_hidden_size_vs_reference(ntm, H):
+    """H = 5 / 24 / 48: the small kernel zero-padded to 8 / 32 / 64; H = 96: the register-resident wide kernel; H = 200:
+    the plain one.  predict per stream == the reference's B = 1 predict, batched forward with state carry, chunked ==
+    one-shot bit for bit."""
+    g = load("g21_any_hidden_size.npz")
+    m = _from_golden(ntm, g, f"sd_{H}_", H, ntm.RNN)
+    assert m.hidden_size == H and tuple(m.GRU.weight_hh_l0.shape) == (3 * H, H)
+    x = dev(g[f"x_{H}"])
+    y = m.predict(x)
+    assert np.abs(y.cpu().numpy() - g[f"y_{H}_predict"]).max() < TOL
+    for b in range(3):
+        assert np.abs(m.predict(x[b:b + 1]).cpu().numpy() - g[f"y_{H}_predict"][b:b + 1]).max() < TOL
+    m.initialize_hidden()
+    y0, y1 = m(x[:, :, :700]), m(x[:, :, 700:])
+    assert np.abs(torch.cat([y0, y1], 2).cpu().numpy() - g[f"y_{H}_carry"]).max() < TOL
+    assert np.abs(m.hidden.cpu().numpy() - g[f"h_{H}_carry"]).max() < TOL
+    assert torch.equal(m.predict(x, segment_length=2048), y) and torch.equal(m.predict(x, segment_length=333), y)
+    for variant in ("lat", "valu"):                     # the variants the small sizes accept all resolve to the same kernel
+        m.kernel_variant = variant
+        assert torch.equal(m.predict(x), y)
+    m.kernel_variant = "mfma2"
+    with pytest.raises(ntm.NtmError):                   # the matrix-pipe variants exist for H = 64 only
+        m.predict(x)
+
+
+@pytest.mark.parametrize("H", [1, 3, 5, 9, 24, 33, 48, 63, 65, 96, 127, 128, 129, 200, 300])
+@pytest.mark.parametrize("B,T", [(1, 1), (7, 63), (9, 64), (5, 65), (70, 129), (131, 400)])
+def test_any_hidden_size_ragged_vs_oracle(ntm, H, B, T):
+    """Ragged batches (B not a multiple of the streams of a wavefront, T around the 64-sample tile), a non-zero initial
+    state, every boundary of the kernel choice (H = 63 | 65, 128 | 129)."""
+    rng = np.random.default_rng(1000 * H + B + T)
+    torch.manual_seed(H)
+    m = ntm.RNN(1, H, 1).to("cuda").eval()
+    w = oracle.Weights.from_state_dict({k: v.cpu().numpy() for k, v in m.state_dict().items()})
+    x = rng.uniform(-0.7, 0.7, (B, T)).astype(np.float32)
+    h0 = rng.uniform(-0.9, 0.9, (B, H)).astype(np.float32)
+    m.hidden = dev(h0).view(1, B, H)
+    y = m(dev(x).unsqueeze(1))
+    yo, ho = oracle.gru_forward(w, x, h0, threads=8)
+    assert np.abs(y[:, 0].cpu().numpy() - yo).max() < TOL and np.abs(m.hidden[0].cpu().numpy() - ho).max() < TOL
+
+
+def test_g21_diffdel_hidden_24(ntm):
+    """DiffDelRNN at a hidden size without a kernel of its own: GRU launch (padded kernel) + the streaming delay pass."""
+    g = load("g21_any_hidden_size.npz")
+    md = int(g["dd_max_delay"])
+    m = _from_golden(ntm, g, "dd_sd_", 24, ntm.DiffDelRNN, max_delay=md)
+    y, pre = m.predict(dev(g["dd_x"]), dev(g["dd_d"]))
+    assert np.abs(pre.cpu().numpy() - g["dd_pre_d"]).max() < TOL and np.abs(y.cpu().numpy() - g["dd_y"]).max() < TOL
+    assert np.abs(m.diffdel.buffer.cpu().numpy() - g["dd_buffer"]).max() < TOL
+    assert np.abs(m.hidden.cpu().numpy() - g["dd_hidden"]).max() < TOL
+    # batched, against the oracle
+    rng = np.random.default_rng(24)
+    B, T = 37, 900
+    x = rng.uniform(-0.6, 0.6, (B, T)).astype(np.float32)
+    d = (150.0 + 120.0 * np.sin(np.arange(T) / 41.0 + rng.uniform(0, 6, (B, 1)))).astype(np.float32)
+    w = oracle.Weights.from_state_dict({k[len("dd_sd_"):]: g[k] for k in g.files if k.startswith("dd_sd_")})
+    yb, pb = m.predict(dev(x).unsqueeze(1), dev(d).unsqueeze(1))
+    yo, po, _, _ = oracle.diffdel_predict(w, x, d, md)
+    assert np.abs(pb[:, 0].cpu().numpy() - po).max() < TOL and np.abs(yb[:, 0].cpu().numpy() - yo).max() < TOL
+    m.delay_mode = "fused"
+    with pytest.raises(ntm.NtmError):                   # the fused step is the H = 64 kernel
+        m.predict(dev(x).unsqueeze(1), dev(d).unsqueeze(1))
+
+
+@pytest.mark.parametrize("H", [24, 96])
+def test_forward_esr_any_hidden_size(ntm, H):
+    """ntm_gru_forward_esr for a size without the matrix-pipe kernel: forward launch + the streaming ESR pass."""
+    rng = np.random.default_rng(H)
+    torch.manual_seed(50 + H)
+    m = ntm.RNN(1, H, 1).to("cuda").eval()
+    w = oracle.Weights.from_state_dict({k: v.cpu().numpy() for k, v in m.state_dict().items()})
+    B, T, skip = 1100, 300, 64
+    x = rng.uniform(-0.6, 0.6, (B, T)).astype(np.float32)
+    t = (0.4 * x + 0.01).astype(np.float32)
+    y, s = m.predict_esr(dev(x).unsqueeze(1), dev(t).unsqueeze(1), skip=skip)
+    rows = [0, 555, B - 1]
+    yo, _ = oracle.gru_predict(w, x[rows])
+    assert np.abs(y[rows, 0].cpu().numpy() - yo).max() < TOL
+    so = oracle.esr_sums(y[rows, 0].cpu().numpy(), t[rows], skip)
+    assert np.abs(s[rows].cpu().numpy() / so - 1).max() < 1e-9
+
+
+def test_any_hidden_size_through_the_c_abi_strided(ntm):
+    """Row strides (the ABI takes them) and NULL h_state through ntm_gru_forward at H = 48 and 96."""
+    L = ntm._lib.lib()
+    from ntm_amd._lib import ptr
+    for H in (48, 96):
+        torch.manual_seed(H)
+        m = ntm.RNN(1, H, 1).to("cuda").eval()
+        w = oracle.Weights.from_state_dict({k: v.cpu().numpy() for k, v in m.state_dict().items()})
+        rng = np.random.default_rng(H)
+        B, T, XS, YS = 6, 150, 170, 190
+        xs = torch.zeros(B, XS, device="cuda")
+        xs[:, :T] = dev(rng.uniform(-0.5, 0.5, (B, T)).astype(np.float32))
+        ys = torch.full((B, YS), 7.0, device="cuda")
+        g, o = m.GRU, m.output
+        rc = L.ntm_gru_forward(ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0), ptr(o.weight), ptr(o.bias),
+                               H, ptr(xs), ptr(ys), B, T, XS, YS, None, ntm._lib.current_stream())
+        assert rc == 0, L.ntm_last_error()
+        yo, _ = oracle.gru_forward(w, xs[:, :T].cpu().numpy())
+        assert np.abs(ys[:, :T].cpu().numpy() - yo).max() < TOL and bool((ys[:, T:] == 7.0).all())
+
+
+# ----------------------------------------------------------------------------- the CLI's loss cache
+def test_cli_loss_cache_with_directory_weights_and_changed_arguments(tmp_path, monkeypatch, capsys):
+    """A `--WEIGHTS` entry that is a directory path (slashes) must not break the cache write after the whole evaluation; a
+    second run with the same arguments loads the cache, one with another --SEGMENT_LENGTH or --KERNEL recomputes, --NO_CACHE
+    neither reads nor writes; a HS[24] checkpoint in the reference's best.pth format runs through the whole command."""
+    from test_cli import _wow_dataset, cli_module
+    cli = cli_module("ntm_cli_r5")
+    g, fs, N, audio, tgt_audio = _wow_dataset(tmp_path, "Wow")
+    monkeypatch.chdir(tmp_path)
+    name = "GRU-HS[24]-L[ESR]-DS[Wow]_1"
+    wdir = tmp_path / "some" / "where" / name
+    wdir.mkdir(parents=True)
+    torch.manual_seed(24)
+    ref = torch.nn.GRU(1, 24, batch_first=True)
+    lin = torch.nn.Linear(24, 1)
+    sd = {"GRU." + k: v.detach().clone() for k, v in ref.state_dict().items()}
+    sd.update({"output." + k: v.detach().clone() for k, v in lin.state_dict().items()})
+    torch.save(sd, str(wdir / "best.pth"))
+    L = 12000
+    argv = ["--MODEL", "GRU", "--WEIGHTS", str(wdir), "--DATASET_DIR", str(tmp_path / "Wow"), "--SUBSET", "Test", "--NO_SHUFFLE",
+            "--SEGMENT_LENGTH", str(L), "--COMPUTE_LOSS", "--NO_EXAMPLE", "--TEMP_PATH", str(tmp_path / "tmp")]
+    got = cli.main(argv)
+    out = capsys.readouterr().out
+    assert "Starting analysis" in out and "Stats:" in out and "cache not written" not in out
+    cache = list((tmp_path / "tmp" / "loss" / "Wow" / "Test").glob("*.npy"))
+    assert len(cache) == 1 and name in cache[0].name and os.sep not in cache[0].name
+    # the numbers: the oracle on the same segments with the same checkpoint
+    T = g["T1"]
+    init = 1 << (int(T.max() * fs) - 1).bit_length()
+    nseg = N // L
+    X = np.stack([audio[k * L:(k + 1) * L] for k in range(nseg)])
+    Tg = np.stack([tgt_audio[k * L:(k + 1) * L] for k in range(nseg)])
+    w = oracle.Weights.from_state_dict({k: v.numpy() for k, v in sd.items()})
+    want = float(np.mean(oracle.esr_per_segment(oracle.gru_predict(w, X)[0], Tg, init)))
+    assert abs(got["ESR"] - want) < 1e-3 * want
+    assert cli.main(argv) == got and "Loading pre-computed!" in capsys.readouterr().out
+    other = cli.main(argv[:argv.index("--SEGMENT_LENGTH") + 1] + ["9000"] + argv[argv.index("--SEGMENT_LENGTH") + 2:])
+    out = capsys.readouterr().out
+    assert "recomputing" in out and "Starting analysis" in out and other["ESR"] != got["ESR"]
+    assert cli.main(argv) != other and "recomputing" in capsys.readouterr().out           # ... and back: the file holds the 9000 run now
+    stamp = cache[0].stat().st_mtime_ns
+    assert cli.main(argv + ["--NO_CACHE"]) == got
+    out = capsys.readouterr().out
+    assert "Starting analysis" in out and cache[0].stat().st_mtime_ns == stamp
+
+
+# ----------------------------------------------------------------------------- chunked TCN call: asynchronous, repeatable, capturable
+def test_chunked_tcn_call_returns_before_its_work_and_can_be_captured(ntm):
+    """the two lane streams of a chunked ntm_tcn_forward were created and destroyed per call (a destroy
+    may wait for the queue).  They are a per-device pool now: the host returns while the device is still busy (host time of
+    the call well under the event-timed duration), repeated calls give the same bits, and the fork / join on pooled streams
+    is capturable into a HIP graph whose replay gives those bits again."""
+    import time
+    L = ntm._lib.lib()
+    B, T = 8, 1 << 23
+    assert L.ntm_tcn_chunk_streams(B, T, 32) == 1          # 8 chunks of one stream on two lanes
+    tcn = ntm.TCN().to("cuda")
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.rand(B, 1, T, generator=g, device="cuda") - 0.5
+    y0 = tcn(x)                                             # builds the pool, sizes the scratch
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    host, devms = [], []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        e0.record()
+        t0 = time.perf_counter()
+        y = tcn(x)
+        host.append(1e3 * (time.perf_counter() - t0))
+        e1.record()
+        torch.cuda.synchronize()
+        devms.append(e0.elapsed_time(e1))
+        assert torch.equal(y, y0)
+    assert min(host) < 0.5 * min(devms), (host, devms)
+    # the same call under stream capture (torch allocates y from the graph's private pool)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(graph, stream=s):
+            yg = tcn(x)
+    torch.cuda.current_stream().wait_stream(s)
+    yg.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(yg, y0)

@@ -77,8 +77,10 @@ def test_cabi_pure_host_entry_points():
     assert L.ntm_tcn_chunk_streams(200, 65536, 32) == 200 and L.ntm_tcn_scratch_floats(200, 65536, 32) == 2 * (200 * 65536 * 32 + 512)
     assert L.ntm_tcn_chunk_streams(3, 1 << 28, 32) == 1            # one stream longer than the budget: that stream alone
     # argument validation happens before anything touches a device
+    assert L.ntm_gru_forward(None, None, None, None, None, None, 1025, None, None, 1, 1, 1, 1, None, None) == -1
+    assert b"[1, 1024]" in L.ntm_last_error()
     assert L.ntm_gru_forward(None, None, None, None, None, None, 24, None, None, 1, 1, 1, 1, None, None) == -1
-    assert b"8, 16, 32 and 64" in L.ntm_last_error()
+    assert b"null pointer" in L.ntm_last_error()                   # round 5: any hidden size in range is accepted
     assert L.ntm_gru_forward(None, None, None, None, None, None, 8, None, None, 1, 1, 1, 1, None, None) == -1
     assert b"null pointer" in L.ntm_last_error()
     # the matrix-pipe variants exist for H = 64 only (checked before any device call)
@@ -92,7 +94,8 @@ def test_cabi_pure_host_entry_points():
     # (round 3 launched the forward first and then returned NTM_EINVAL with y half-written)
     assert L.ntm_gru_forward_esr(one, one, one, one, one, None, 64, one, one, 4, 100, 100, 128, None, two, 0, one, None) == -1
     assert b"contiguous y rows" in L.ntm_last_error()
-    assert L.ntm_gru_forward_esr(one, one, one, one, one, None, 24, one, one, 4, 100, 100, 100, None, two, 0, one, None) == -1
+    assert L.ntm_gru_forward_esr(one, one, one, one, one, None, 2000, one, one, 4, 100, 100, 100, None, two, 0, one, None) == -1
+    assert b"[1, 1024]" in L.ntm_last_error()
     assert L.ntm_gru_forward_esr(one, one, one, one, one, None, 64, one, None, 4, 100, 100, 100, None, two, 0, one, None) == -1
     assert b"null pointer" in L.ntm_last_error()
     # the DiffDelGRU entries check signs first (a negative B used to reach a launch with (unsigned)B blocks), B == 0 is a no-op
@@ -135,15 +138,16 @@ def test_state_dict_protocol():
     with pytest.raises(RuntimeError):                          # strict load like torch: bias key missing
         m.load_state_dict(ntm_amd.weights.load_state_dict(ntm_amd.weights.W_DIFFDEL))
     # the reference's own defaults construct (code/model.py:22: hidden_size=8; code/train.py:50: 16)
-    for H in (8, 16, 32):
+    for H in (8, 16, 32, 5, 24, 48, 96, 200):                   # round 5: ANY hidden size (`--HIDDEN_SIZE`, code/train.py:50)
         r = ntm_amd.RNN() if H == 8 else ntm_amd.RNN(1, H, 1)
         assert r.hidden_size == H and tuple(r.GRU.weight_hh_l0.shape) == (3 * H, H)
         assert sum(p.numel() for p in r.parameters()) == 3 * H * H + 3 * H + 6 * H + H + 1
         torch_ref = torch.nn.GRU(1, H, batch_first=True)
         assert {k: tuple(v.shape) for k, v in r.GRU.state_dict().items()} == \
                {k: tuple(v.shape) for k, v in torch_ref.state_dict().items()}
-    with pytest.raises(ValueError):
-        ntm_amd.RNN(1, 24, 1)                                  # not one of the compiled sizes
+    for bad in (0, -3, 1025, 2.5):
+        with pytest.raises(ValueError):
+            ntm_amd.RNN(1, bad, 1)                             # outside [1, NTM_MAX_HIDDEN] / not an integer
 
 
 def test_no_cpu_fallback():

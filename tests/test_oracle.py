@@ -222,6 +222,32 @@ def test_g16_diffdel_hidden_16():
     assert np.abs(buf - g["dd_buffer"][:, 0, :]).max() < GRU_TOL and np.abs(h - g["dd_hidden"][0]).max() < GRU_TOL
 
 
+@pytest.mark.parametrize("H", [5, 24, 48, 96, 200])
+def test_g21_any_hidden_size(H):
+    """`--HIDDEN_SIZE` is a free integer in the reference (code/train.py:50): its RNN at sizes that are neither a power of
+    two nor <= 64 (golden g21, tools/make_goldens_anyh.py), predict per stream and batched forward with state carry."""
+    g = load("g21_any_hidden_size.npz")
+    w = _g16_weights(g, f"sd_{H}_")
+    assert w.H == H and w.b_o is not None
+    x = g[f"x_{H}"][:, 0, :]
+    y, _ = oracle.gru_predict(w, x)
+    assert np.abs(y - g[f"y_{H}_predict"][:, 0, :]).max() < GRU_TOL
+    y0, h = oracle.gru_forward(w, x[:, :700])
+    y1, h = oracle.gru_forward(w, x[:, 700:], h)
+    assert np.abs(np.concatenate([y0, y1], 1) - g[f"y_{H}_carry"][:, 0, :]).max() < GRU_TOL
+    assert np.abs(h - g[f"h_{H}_carry"][0]).max() < GRU_TOL
+
+
+def test_g21_diffdel_hidden_24():
+    g = load("g21_any_hidden_size.npz")
+    w = _g16_weights(g, "dd_sd_")
+    assert w.H == 24 and w.b_o is None
+    y, pre, h, buf = oracle.diffdel_predict(w, g["dd_x"][:, 0, :], g["dd_d"][:, 0, :], int(g["dd_max_delay"]))
+    assert np.abs(pre - g["dd_pre_d"][:, 0, :]).max() < GRU_TOL
+    assert np.abs(y - g["dd_y"][:, 0, :]).max() < GRU_TOL
+    assert np.abs(buf - g["dd_buffer"][:, 0, :]).max() < GRU_TOL and np.abs(h - g["dd_hidden"][0]).max() < GRU_TOL
+
+
 def test_oracle_under_address_and_ub_sanitizers():
     """SURVEY.md 5 asks for a CPU sanitizer build of the restatement: `make -C oracle asan` (ASan + UBSan), every entry
     point exercised in a child process with the sanitizer runtime preloaded (tests/asan_driver.py)."""

@@ -194,8 +194,9 @@ int main(int argc, char **argv)
     if (ntm_abi_version() != NTM_ABI_VERSION) { fprintf(stderr, "unexpected ABI version\n"); return 4; }
     int rc = ntm_gru_forward(w_ih, w_hh, b_ih, b_hh, w_o, b_o, NTM_HIDDEN, dx, dy, B, T, T, T, dh, stream);
     if (rc != NTM_OK) { fprintf(stderr, "ntm_gru_forward: %d %s\n", rc, ntm_last_error()); return 5; }
-    // error path: a hidden size that is not compiled (8, 16, 32, 64 are) must be refused with a message, not crash
-    if (ntm_gru_forward(w_ih, w_hh, b_ih, b_hh, w_o, b_o, 24, dx, dy, B, T, T, T, dh, stream) == NTM_OK) return 6;
+    // error path: a hidden size outside [1, NTM_MAX_HIDDEN] must be refused with a message, not crash
+    if (ntm_gru_forward(w_ih, w_hh, b_ih, b_hh, w_o, b_o, NTM_MAX_HIDDEN + 1, dx, dy, B, T, T, T, dh, stream) == NTM_OK) return 6;
+    if (ntm_gru_forward(w_ih, w_hh, b_ih, b_hh, w_o, b_o, 0, dx, dy, B, T, T, T, dh, stream) == NTM_OK) return 6;
     // forward + the ESR sums of the loss loop in ONE call (ntm_gru_forward_esr; target = the input here), against the
     // streaming pass on the same output: the sums agree to fp64 summation order
     double *e1, *e2;

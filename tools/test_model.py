@@ -24,7 +24,7 @@ Paths: `--DATASET <name>` is looked up under `--AUDIO_PATH` (default ../audio/, 
 (ntm_amd.weights.available()).  Delay trajectories come from the `trajectory_<id>_*.npy` side-cars, which the feeder
 computes and caches on first use for stereo datasets exactly as DelayAnalyzer does; `--MAX_DELAY` (seconds) overrides
 the dataset's measured maximum.  Extra flags of this build: --DATASET_DIR --AUDIO_PATH --MODEL_PATH --RESULTS_PATH
---TEMP_PATH --BATCH_SIZE --STREAM_CHUNK --MAX_DELAY --INIT_LEN --KERNEL --SEED --NO_EXAMPLE.
+--TEMP_PATH --NO_CACHE --BATCH_SIZE --STREAM_CHUNK --MAX_DELAY --INIT_LEN --KERNEL --SEED --NO_EXAMPLE.
 """
 import argparse
 import os
@@ -94,6 +94,7 @@ def build_parser():
     p.add_argument('--MODEL_PATH', type=str, default="../weights/")
     p.add_argument('--RESULTS_PATH', type=str, default="../results/")
     p.add_argument('--TEMP_PATH', type=str, default=".temp/", help="where the loss results are cached (code/test-model.py:304-320)")
+    p.add_argument('--NO_CACHE', action='store_true', default=False, help="neither read nor write the loss cache under TEMP_PATH")
     p.add_argument('--BATCH_SIZE', type=int, default=4096, help="segments per launch (the matrix-pipe kernel wants thousands)")
     p.add_argument('--STREAM_CHUNK', type=int, default=8192, help="time chunk of the host->device pipeline; 0 = whole-batch copies")
     p.add_argument('--MAX_DELAY', type=float, default=0.0, help="seconds (DelayAnalyzer.max_delay of the dataset)")
@@ -203,7 +204,7 @@ def main(argv=None):
 
     results = {}
     if a.COMPUTE_LOSS:
-        results = compute_loss(a, feeder, model, name, delay, is_dd, init_len, rank, world, say)
+        results = compute_loss(a, feeder, model, [m["weight"] for m in models], delay, is_dd, init_len, rank, world, say)
     else:
         say(f"{len(feeder)} segments of {feeder.length} samples @ {fs} Hz; no loss without --COMPUTE_LOSS")
     if rank == 0 and not a.NO_EXAMPLE:
@@ -211,18 +212,42 @@ def main(argv=None):
     return results
 
 
-def compute_loss(a, feeder, model, name, delay, is_dd, init_len, rank, world, say):
-    """code/test-model.py:296-418: per-segment losses, mean over segments, cached under TEMP_PATH as upstream."""
+def loss_cache_key(a, feeder, names, init_len):
+    """Everything that changes the numbers of the loss loop but is not in upstream's cache file name
+    (code/test-model.py:301-304 keys on WEIGHTS / ADD_DELAY / DEMODULATE / ADD_NOISE + dataset basename + subset): stored
+    INSIDE the cache file and compared on load, so a run with another segment length, seed, kernel ... recomputes."""
+    return {"weights": list(names), "dataset": os.path.abspath(dataset_path(a)), "subset": str(feeder.subset),
+            "segment_length": int(feeder.length), "segments": int(len(feeder)), "fraction": float(a.FRACTION),
+            "shuffle": not a.NO_SHUFFLE, "seed": a.SEED, "sync": float(a.SYNC), "init_len": int(init_len),
+            "max_delay": float(a.MAX_DELAY), "kernel": str(a.KERNEL), "add_delay": bool(a.ADD_DELAY),
+            "demodulate": bool(a.DEMODULATE), "add_noise": bool(a.ADD_NOISE)}
+
+
+def compute_loss(a, feeder, model, names, delay, is_dd, init_len, rank, world, say):
+    """code/test-model.py:296-418: per-segment losses, mean over segments, cached under TEMP_PATH as upstream.
+    `names`: the resolved weight names of --WEIGHTS (a --WEIGHTS entry may be a directory path: its slashes must not reach
+    the cache file name)."""
     fs = feeder.fs
     say("\nComputing loss over dataset ...", end="")
     save_path = os.path.join(a.TEMP_PATH, 'loss', f"{dataset_name(a)}", f"{feeder.subset}")
-    save_name = f"{a.WEIGHTS}_DELAY[{a.ADD_DELAY}]_DEMODULATE[{a.DEMODULATE}]_NOISE[{a.ADD_NOISE}].npy"
+    safe = [str(n).replace(os.sep, "_").replace("/", "_") for n in names]
+    save_name = f"{safe}_DELAY[{a.ADD_DELAY}]_DEMODULATE[{a.DEMODULATE}]_NOISE[{a.ADD_NOISE}].npy"
     cached = os.path.join(save_path, save_name)
-    if os.path.exists(cached):
-        say(" Loading pre-computed!")
-        results = np.load(cached, allow_pickle=True).item()
-        n_seg = len(feeder)
-    else:
+    key = loss_cache_key(a, feeder, names, init_len)
+    results = None
+    if os.path.exists(cached) and not a.NO_CACHE:
+        # every rank takes the same decision: it depends on the file and the arguments only
+        try:
+            blob = np.load(cached, allow_pickle=True).item()
+        except Exception:
+            blob = None
+        if isinstance(blob, dict) and blob.get("_key") == key:
+            say(" Loading pre-computed!")
+            results = {k: v for k, v in blob.items() if not k.startswith("_")}
+            n_seg = blob.get("_segments", len(feeder))
+        else:
+            say(" (cached results belong to other arguments: recomputing)", end="")
+    if results is None:
         say(" Starting analysis...")
         per = {"ESR": [], "DCPreESR": [], "MultiSTFT": []}
         mrstft = ntm_amd.MRSTFTLoss()
@@ -264,9 +289,12 @@ def compute_loss(a, feeder, model, name, delay, is_dd, init_len, rank, world, sa
                for k, v in per.items()}
         n_seg = res['ESR']['segments']
         results = {k: v["mean_segment_loss"] for k, v in res.items()}
-        if rank == 0:
-            os.makedirs(save_path, exist_ok=True)
-            np.save(cached, results)
+        if rank == 0 and not a.NO_CACHE:
+            try:                                   # a cache that cannot be written must never cost the printed results
+                os.makedirs(save_path, exist_ok=True)
+                np.save(cached, dict(results, _key=key, _segments=n_seg))
+            except OSError as e:
+                say(f"(loss cache not written: {e})")
     say()
     say("=" * 5, "Stats:", "=" * 5)
     say(f"Model:      {a.WEIGHTS}")
