@@ -289,6 +289,142 @@ def measure_workload(workload, B, T, steps, warmup, check, dev, threads=1, delay
     torch.cuda.empty_cache()
     return res
 
+CLI_WEIGHTS = "GRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE_WOWFLUTTER]_BEST"
+CLI_DATASET = "ReelToReel_Dataset_MiniPulse100_CHOWTAPE_WOWFLUTTER"
+
+
+def cli_dataset(root, n_seg, L, dev):
+    """The dataset the CLI line runs on, in the on-disk format of the reference's Zenodo sets (code/dataset.py:129-293): one
+    stereo float32 WAV pair `<root>/audio/<name>/Test/{input,target}_1_.wav` (channel 0 audio, channel 1 the pilot track) of
+    n_seg x L samples, and its `trajectory_1_.npy` side-car (the pickled dict DelayAnalyzer caches, utilities.py:327-335) with a
+    wow-and-flutter trajectory around 27 ms like the toy data.  Synthesised on the device, written with scipy.
+    -> (dataset directory, dict of host arrays for the CPU port)."""
+    from scipy.io import wavfile
+    from ntm_amd.feeder import write_sidecar
+    N = n_seg * L + 777
+    g = torch.Generator(device=dev)
+    g.manual_seed(2025)
+    n = torch.arange(N, device=dev, dtype=torch.float32)
+    f0 = 220.0 * (1.0 + 0.3 * torch.sin(2 * np.pi * 0.2 * n / FS))
+    phase = torch.cumsum(f0.double(), 0) * (2 * np.pi / FS)
+    audio = (0.4 * torch.sin(phase).float() * (0.6 + 0.4 * torch.sin(2 * np.pi * 0.5 * n / FS))
+             + 0.02 * torch.randn(N, generator=g, device=dev))
+    tgt = 0.5 * torch.tanh(2.0 * torch.roll(audio, int(0.0271 * FS)))
+    traj = (0.0271 + 0.004 * torch.sin(2 * np.pi * 1.3 * n / FS) + 0.0005 * torch.sin(2 * np.pi * 23 * n / FS)).double().cpu().numpy()
+    a, t = audio.cpu().numpy(), tgt.cpu().numpy()
+    del n, f0, phase, audio, tgt
+    d = os.path.join(root, "audio", CLI_DATASET, "Test")
+    os.makedirs(d)
+    pilot = np.zeros(N, np.float32)
+    wavfile.write(os.path.join(d, "input_1_.wav"), FS, np.stack([a, pilot], 1))
+    wavfile.write(os.path.join(d, "target_1_.wav"), FS, np.stack([t, pilot], 1))
+    peaks = np.arange(1000, N - 10000, 4410)
+    meta = {"reconstruction_percentage": 0.0, "wiggle_percentage": 0.0}
+    write_sidecar(os.path.join(d, "trajectory_1_.npy"), peaks, peaks + int(0.0271 * FS), traj, meta, meta)
+    return os.path.join(root, "audio", CLI_DATASET), {"audio": a, "target": t, "traj": traj}
+
+
+def cli_cpu_port(host, L, n_sub, init_len, max_delay_n, cores):
+    """CPU leg (the oracle and stock torch are the things timed here, never the product): the SAME command in the
+    reference's terms -- torch.nn.GRU + Linear under inference_mode (code/model.py:44-45,81-82), the delay line, the three
+    losses -- on the first `n_sub` segments of the dataset, stage by stage, on `cores` threads."""
+    import oracle
+    from ntm_amd import weights
+    sd = weights.load_state_dict(CLI_WEIGHTS)
+    w = oracle.Weights.from_state_dict({k: v.numpy() for k, v in sd.items()})
+    torch.set_num_threads(cores)
+    X = np.stack([host["audio"][k * L:(k + 1) * L] for k in range(n_sub)])
+    Tg = np.stack([host["target"][k * L:(k + 1) * L] for k in range(n_sub)])
+    Dt = np.stack([host["traj"][k * L:(k + 1) * L].astype(np.float32) * np.float32(FS) for k in range(n_sub)])
+    st = {}
+    t0 = time.perf_counter()
+    y, _ = oracle.torch_gru_port(w)(X, np.repeat(oracle.warm_state(w), n_sub, 0))
+    st["predict_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    yd, _ = oracle.delay_forward(y, Dt, np.zeros((n_sub, max_delay_n), np.float32))
+    st["apply_delay_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    esr = oracle.esr_per_segment(yd, Tg, init_len)
+    st["ESR_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    sdc = oracle.esr_dcpre_sums(yd, Tg, init_len)
+    st["DCPreESR_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    mr = oracle.mrstft_per_segment(yd, Tg, init_len)
+    st["MultiSTFT_s"] = time.perf_counter() - t0
+    n = L - init_len
+    total = sum(st.values())
+    return {"kind": "port", "cores": cores, "sample": f"the first {n_sub} of the dataset's segments ({n_sub} x {L} samples), every stage of the command "
+            "after the decode: torch.nn.GRU+Linear on CPU under inference_mode, then the C oracle's delay line / ESR / DCPreESR and "
+            "its torch.stft MultiSTFT", "stages_s": st, "value": n_sub * L / total, "unit": "samples/s",
+            "losses": {"ESR": float(np.mean(esr)), "DCPreESR": float(np.mean((sdc[:, 0] / n) / (sdc[:, 1] / n + 1e-5))),
+                       "MultiSTFT": float(np.mean(mr))}}
+
+
+def cli_workload(dev, check, n_seg=128, L=441000):
+    """`other_workloads.cli`: the reference's canonical evaluation command (scripts/test-model-loss.sh:22,57-63: 10-second
+    segments, --ADD_DELAY, --COMPUTE_LOSS = ESR + DCPreESR + MultiSTFT, code/test-model.py:250-254) through tools/test_model.py,
+    end to end from WAV files on disk, on a synthetic dataset in the reference's on-disk format; stage times from HIP events
+    / host clocks inside the command (tools/test_model.py StageTimes), the second of two runs (the first pays library load,
+    allocator growth and the page cache).  -> dict."""
+    import importlib.util
+    import shutil
+    import tempfile
+    spec = importlib.util.spec_from_file_location("ntm_cli_bench", os.path.join(ROOT, "tools", "test_model.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    tmp = tempfile.mkdtemp(prefix="ntm_cli_", dir="/tmp")
+    cwd = os.getcwd()
+    try:
+        t0 = time.perf_counter()
+        ds_dir, host = cli_dataset(tmp, n_seg, L, dev)
+        t_make = time.perf_counter() - t0
+        os.makedirs(os.path.join(tmp, "scripts"))
+        os.chdir(os.path.join(tmp, "scripts"))           # the command resolves ../audio/<DATASET> like the reference (:107,147)
+        argv = ["--MODEL", "GRU", "--WEIGHTS", CLI_WEIGHTS, "--DATASET", CLI_DATASET, "--SUBSET", "Test", "--NO_SHUFFLE",
+                "--SEGMENT_LENGTH", str(L), "--ADD_DELAY", "--COMPUTE_LOSS", "--NO_CACHE", "--NO_EXAMPLE"]
+        import contextlib
+        import io
+        runs = []
+        for _ in range(2):
+            prof = {}
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                losses = cli.main(argv, profile=prof)
+            torch.cuda.synchronize()
+            prof["command_s"] = time.perf_counter() - t0
+            runs.append((prof, losses))
+        prof, losses = runs[-1]
+        gpu_ms = sum(v for k, v in prof.items() if k.endswith("_ms") and k != "h2d_ms")
+        stages = {"decode (WAV -> pinned host, side-car)": prof["decode_s"] * 1e3, "h2d": prof.get("h2d_ms", 0.0),
+                  "predict": prof.get("predict_ms", 0.0) + prof.get("predict_streamed_ms", 0.0), "apply_delay": prof.get("apply_delay_ms", 0.0),
+                  "ESR": prof["ESR_ms"], "DCPreESR": prof["DCPreESR_ms"], "MultiSTFT": prof.get("MultiSTFT_ms", 0.0)}
+        bound = max(stages, key=stages.get)
+        samples = float(prof["segments"]) * prof["segment_length"]
+        res = {"workload": f"tools/test_model.py {' '.join(argv[:-2])}: {prof['segments']} segments x {L} samples (10 s at 44.1 kHz) from "
+                           f"a stereo float32 WAV pair + trajectory side-car on disk ({2 * 8 * samples / 1e9:.2f} GB), GRU-HS[64] predict, delay "
+                           "line, ESR + DCPreESR + MultiSTFT, mean over segments",
+               "reference_command": "scripts/test-model-loss.sh:57-63 (SEGMENT_LENGTH :22)",
+               "value": samples / prof["command_s"], "unit": "samples/s", "command_s": prof["command_s"],
+               "first_run_command_s": runs[0][0]["command_s"], "dataset_synthesis_s_untimed": t_make,
+               "stages_ms": stages, "h2d_GBps": (prof.get("h2d_bytes", 0) / 1e9) / (prof["h2d_ms"] * 1e-3) if prof.get("h2d_ms") else None,
+               "loss_loop_s": prof.get("loss_loop_s"), "gpu_kernel_ms": gpu_ms,
+               "gpu_busy_fraction_of_loss_loop": gpu_ms * 1e-3 / prof["loss_loop_s"] if prof.get("loss_loop_s") else None,
+               "gpu_busy_fraction_of_command": gpu_ms * 1e-3 / prof["command_s"],
+               "bound_by": bound, "losses": {k: float(v) for k, v in losses.items()},
+               "kernel": "gru_lat_kernel (128 segments <= NTM_GRU_LAT_MAX_B)" if prof["segments"] <= 1024 else "gru_mfma2_kernel"}
+        if check:
+            md = int(1.25 * float(host["traj"].max()) * FS)
+            init_len = 1 << (int(float(host["traj"].max()) * FS) - 1).bit_length()
+            cpu = cli_cpu_port(host, L, 2, init_len, md, _host_threads())
+            res["cpu_baseline"] = cpu
+            res["speedup_vs_cpu_after_decode"] = (samples / (prof["command_s"] - prof["decode_s"])) / cpu["value"]
+        return res
+    finally:
+        os.chdir(cwd)
+        shutil.rmtree(tmp, ignore_errors=True)
+
 
 def side_workload(a):
     """`--workload diffdel | tcn`: BASELINE configs[2] / configs[3] at the headline's batch as a line of their own
@@ -332,6 +468,12 @@ def other_workloads(a, dev, check):
         except Exception as e:          # a side workload must never take the headline line down with it (e.g. out of memory
             out[key] = {"error": f"{type(e).__name__}: {e}"[:500]}      # on a box that is shared or smaller than expected)
             torch.cuda.empty_cache()
+    if a.cli_segments > 0:
+        try:
+            out["cli"] = cli_workload(dev, check, n_seg=a.cli_segments)
+        except Exception as e:
+            out["cli"] = {"error": f"{type(e).__name__}: {e}"[:500]}
+        torch.cuda.empty_cache()
     return out
 
 
@@ -536,6 +678,8 @@ def main():
     ap.add_argument("--other-gru-batches", type=lambda v: [int(t) for t in v.split(",") if t], default=[8192, 16384, 32768])
     ap.add_argument("--other-tcn-batches", type=lambda v: [int(t) for t in v.split(",") if t], default=[8192, 16384],
                     help="TCN legs at the per-GPU shapes of configs[4] (they did not fit before the forward was chunked by streams)")
+    ap.add_argument("--cli-segments", type=int, default=128,
+                    help="other_workloads.cli: the evaluation command end to end on this many 10-second segments (0 = skip)")
     ap.add_argument("--workload", default="gru", choices=["gru", "diffdel", "tcn"],
                     help="gru = BASELINE configs[1] (the headline metric); diffdel = configs[2]; tcn = configs[3]")
     ap.add_argument("--launch-check", action="store_true", help=argparse.SUPPRESS)
@@ -857,18 +1001,22 @@ def main():
     }
     info = os.path.join(ROOT, "neural-tape-modeling_amd", "build_info.json")      # written by __graft_entry__.build()
     bi = None
+    # (read only: the record is written next to the library by its Makefile, so that this process -- which has initialised the
+    # GPU, possibly under a profiler -- never starts compiler tools)
     try:
-        if os.path.exists(info) and os.path.getmtime(info) >= os.path.getmtime(ntm_amd._lib.LIB_PATH):
-            bi = json.load(open(info))
-        else:                                     # no record of THIS library: read its code objects now
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import kernel_resources
-            bi = kernel_resources.build_info(ntm_amd._lib.LIB_PATH)
-    except Exception as e:                        # the record is a courtesy: never at the cost of the line
-        out["build"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+        import hashlib
+        bi = json.load(open(info))
+        with open(ntm_amd._lib.LIB_PATH, "rb") as f:
+            if hashlib.sha256(f.read()).hexdigest() != bi.get("library_sha256"):
+                bi = None
+                out["build"] = {"error": "build_info.json describes another libntm.so: run `make -C neural-tape-modeling_amd/csrc`"}
+    except (OSError, ValueError) as e:
+        bi = None
+        out["build"] = {"error": f"build_info.json: {type(e).__name__}: {e}"[:200]}
     if bi is not None:
         want = roofline["kernel"].split("<")[0]
         out["build"] = {"compiler": bi.get("compiler"), "arch": bi.get("arch"), "git_head_at_build": bi.get("git_head_at_build"),
+                        "library_sha256": bi.get("library_sha256"),
                         "runtime_hip": torch.version.hip,
                         "kernels": [{k: v for k, v in kk.items() if k != "symbol"} for kk in bi.get("kernels", [])
                                     if want in kk["kernel"] or "gru_lat_kernel" in kk["kernel"]]}

@@ -406,12 +406,14 @@ class SegmentFeeder:
                 a.record_stream(side)
         return y, x, t
 
-    def batches(self, batch_size, device="cuda", rank=0, world=1, prefetch=True):
+    def batches(self, batch_size, device="cuda", rank=0, world=1, prefetch=True, timing=None):
         """Yield (input (B,1,L), target (B,1,L) | None, d_traj_seconds (B,1,L) | None, metas) on `device`
         for this rank's contiguous shard of the segments.  On a HIP device consecutive segments of a file are
         one contiguous run of pinned host memory, so a batch is a handful of large async DMA copies issued on a
         side stream while the caller still computes on the previous batch (`prefetch`); the consumer's stream only
-        waits for the copy event of the batch it is handed.  (Demodulated targets take the per-item path.)"""
+        waits for the copy event of the batch it is handed.  (Demodulated targets take the per-item path.)
+        `timing`: optional list; every staged batch appends (start event, end event, bytes) recorded on the copy stream
+        around its host-to-device copies (the evaluation CLI's stage times)."""
         from .distributed import shard_range
         lo, hi = shard_range(len(self), rank, world)
         on_gpu = torch.cuda.is_available() and torch.device(device).type == "cuda"
@@ -471,9 +473,14 @@ class SegmentFeeder:
                 out, metas, keep = fn(b0)
                 return out, metas, None, keep
             with torch.cuda.stream(copy_stream):
+                if timing is not None:
+                    t0 = torch.cuda.Event(enable_timing=True)
+                    t0.record(copy_stream)
                 out, metas, keep = fn(b0)
-                ev = torch.cuda.Event()
+                ev = torch.cuda.Event(enable_timing=timing is not None)
                 ev.record(copy_stream)
+                if timing is not None:
+                    timing.append((t0, ev, sum(a.numel() * 4 for a in out if a is not None)))
             return out, metas, ev, keep          # `keep` holds pinned staging buffers alive until the batch is consumed
 
         starts = list(range(lo, hi, batch_size))

@@ -225,3 +225,23 @@ def test_chunked_tcn_call_returns_before_its_work_and_can_be_captured(ntm):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(yg, y0)
+
+
+# ----------------------------------------------------------------------------- other_workloads.cli of the bench line
+def test_bench_cli_workload_stage_times_and_cpu_port():
+    """bench.py's `other_workloads.cli` (the reference's evaluation command end to end, scripts/test-model-loss.sh:57-63) at a
+    small shape: two 1-second segments, so that the command's losses can be compared with the torch-CPU port of the same
+    command on the same two segments; every stage carries a time, the GPU-busy fractions are fractions."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    r = bench.cli_workload(torch.device("cuda", 0), True, n_seg=2, L=44100)
+    assert r["unit"] == "samples/s" and r["value"] > 0 and abs(r["value"] - 2 * 44100 / r["command_s"]) < 1e-6 * r["value"]
+    assert set(r["stages_ms"]) == {"decode (WAV -> pinned host, side-car)", "h2d", "predict", "apply_delay", "ESR", "DCPreESR", "MultiSTFT"}
+    assert all(v > 0 for v in r["stages_ms"].values()) and r["bound_by"] in r["stages_ms"]
+    assert 0 < r["gpu_busy_fraction_of_command"] <= r["gpu_busy_fraction_of_loss_loop"] <= 1.0
+    cpu = r["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and set(cpu["stages_s"]) == {"predict_s", "apply_delay_s", "ESR_s", "DCPreESR_s", "MultiSTFT_s"}
+    for k in ("ESR", "DCPreESR", "MultiSTFT"):           # same command, same two segments: the CPU port's losses
+        assert abs(r["losses"][k] / cpu["losses"][k] - 1) < 2e-3, (k, r["losses"], cpu["losses"])
+    assert "scripts/test-model-loss.sh" in r["reference_command"] and not os.path.exists("/tmp/ntm_cli_leftover")

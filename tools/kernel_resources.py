@@ -100,7 +100,10 @@ def build_info(lib_path=DEFAULT_LIB):
         src = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=30).stdout.strip() or None
     except (OSError, subprocess.TimeoutExpired):
         src = None
-    return {"library": os.path.relpath(lib_path, ROOT), "compiler": hipcc_version(), "arch": "gfx950", "git_head_at_build": src,
+    import hashlib
+    with open(lib_path, "rb") as f:
+        digest = hashlib.sha256(f.read()).hexdigest()
+    return {"library": os.path.relpath(lib_path, ROOT), "library_sha256": digest, "compiler": hipcc_version(), "arch": "gfx950", "git_head_at_build": src,
             "kernels": sorted(ks, key=lambda k: k["kernel"])}
 
 

@@ -28,6 +28,7 @@ the dataset's measured maximum.  Extra flags of this build: --DATASET_DIR --AUDI
 """
 import argparse
 import os
+import time
 import sys
 
 import numpy as np
@@ -155,7 +156,31 @@ def write_wav16(path, x, fs):
     wavfile.write(path, int(fs), np.clip(np.rint(x * 32767.0), -32768, 32767).astype(np.int16))
 
 
-def main(argv=None):
+class StageTimes:
+    """Stage times of one loss run (`main(argv, profile={})`; bench.py's `other_workloads.cli`): HIP events around every
+    stage of every batch on the compute stream, host clocks around the dataset decode and the whole loop."""
+
+    def __init__(self):
+        self.events, self.h2d, self.host = {}, [], {}
+
+    def span(self, name):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.events.setdefault(name, []).append((e0, e1))
+        e0.record()
+        return e1
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {k + "_ms": sum(a.elapsed_time(b) for a, b in v) for k, v in self.events.items()}
+        if self.h2d:
+            out["h2d_ms"] = sum(a.elapsed_time(b) for a, b, _ in self.h2d)
+            out["h2d_bytes"] = sum(n for _, _, n in self.h2d)
+        out.update(self.host)
+        return out
+
+
+def main(argv=None, profile=None):
+    """`profile`: a dict that receives the stage times of the loss run (StageTimes.summary); None = no instrumentation."""
     a = parse_args(argv)
     rank, world, local = D.init_from_env()
     say = print if rank == 0 else (lambda *x, **k: None)
@@ -173,9 +198,14 @@ def main(argv=None):
 
     # ---- dataset (code/test-model.py:145-154,178-179)
     say("Dataset (audio)")
+    t_decode = time.perf_counter()
     feeder = SegmentFeeder(dataset_path(a), subset=a.SUBSET, length=a.SEGMENT_LENGTH, sync=a.SYNC, demodulate=a.DEMODULATE,
                            fraction=a.FRACTION, shuffle=not a.NO_SHUFFLE, seed=a.SEED)
     fs = feeder.fs
+    stages = StageTimes() if profile is not None else None
+    if stages is not None:      # WAV decode into pinned host memory + trajectory side-cars (read, or analysed on first use)
+        stages.host["decode_s"] = time.perf_counter() - t_decode
+        stages.host["segments"], stages.host["segment_length"] = len(feeder), feeder.length
     if a.MAX_DELAY <= 0 and feeder.max_delay > 0:          # dataset.delay_analyzer.max_delay (code/test-model.py:223,323-324)
         a.MAX_DELAY = feeder.max_delay
 
@@ -204,7 +234,9 @@ def main(argv=None):
 
     results = {}
     if a.COMPUTE_LOSS:
-        results = compute_loss(a, feeder, model, [m["weight"] for m in models], delay, is_dd, init_len, rank, world, say)
+        results = compute_loss(a, feeder, model, [m["weight"] for m in models], delay, is_dd, init_len, rank, world, say, stages)
+        if stages is not None:
+            profile.update(stages.summary())
     else:
         say(f"{len(feeder)} segments of {feeder.length} samples @ {fs} Hz; no loss without --COMPUTE_LOSS")
     if rank == 0 and not a.NO_EXAMPLE:
@@ -223,7 +255,7 @@ def loss_cache_key(a, feeder, names, init_len):
             "demodulate": bool(a.DEMODULATE), "add_noise": bool(a.ADD_NOISE)}
 
 
-def compute_loss(a, feeder, model, names, delay, is_dd, init_len, rank, world, say):
+def compute_loss(a, feeder, model, names, delay, is_dd, init_len, rank, world, say, stages=None):
     """code/test-model.py:296-418: per-segment losses, mean over segments, cached under TEMP_PATH as upstream.
     `names`: the resolved weight names of --WEIGHTS (a --WEIGHTS entry may be a directory path: its slashes must not reach
     the cache file name)."""
@@ -237,16 +269,20 @@ def compute_loss(a, feeder, model, names, delay, is_dd, init_len, rank, world, s
     results = None
     if os.path.exists(cached) and not a.NO_CACHE:
         # every rank takes the same decision: it depends on the file and the arguments only
+        why = "unreadable"
         try:
             blob = np.load(cached, allow_pickle=True).item()
-        except Exception:
-            blob = None
+        except Exception as e:
+            blob, why = None, f"unreadable: {type(e).__name__}"
         if isinstance(blob, dict) and blob.get("_key") == key:
             say(" Loading pre-computed!")
             results = {k: v for k, v in blob.items() if not k.startswith("_")}
             n_seg = blob.get("_segments", len(feeder))
         else:
-            say(" (cached results belong to other arguments: recomputing)", end="")
+            if isinstance(blob, dict):
+                old = blob.get("_key") or {}
+                why = "differs in " + ", ".join(sorted(k for k in set(old) | set(key) if old.get(k) != key.get(k))) if old else "no argument record"
+            say(f" (cached results belong to other arguments [{why}]: recomputing)", end="")
     if results is None:
         say(" Starting analysis...")
         per = {"ESR": [], "DCPreESR": [], "MultiSTFT": []}
@@ -254,33 +290,47 @@ def compute_loss(a, feeder, model, names, delay, is_dd, init_len, rank, world, s
         seg_len = feeder.length - (int(feeder.mean_delay * fs) if a.DEMODULATE else 0)    # demodulation trims the tail
         with_stft = seg_len - init_len > 1024                  # the largest STFT frame needs > 1024 samples
 
+        span = (lambda name: stages.span(name)) if stages is not None else (lambda name: None)
+        done = lambda e: e.record() if e is not None else None                       # noqa: E731
+        t_loop = time.perf_counter()
+
         def batches():
             if a.DEMODULATE or a.ADD_DELAY or a.STREAM_CHUNK <= 0:
-                for xin, tgt, dt, _ in feeder.batches(a.BATCH_SIZE, "cuda", rank, world):
+                for xin, tgt, dt, _ in feeder.batches(a.BATCH_SIZE, "cuda", rank, world, timing=None if stages is None else stages.h2d):
+                    e = span("predict")
                     if is_dd:
                         assert dt is not None, "DiffDelGRU needs trajectory_<id>_*.npy side-cars"
                         out, _ = model.predict(xin, dt * fs)
                     else:
                         out = model.predict(xin)
+                    done(e)
                     yield xin, tgt, out, dt
             else:
                 # predict straight from the feeder's pinned files, H2D copies pipelined along time under the launches
                 lo, hi = D.shard_range(len(feeder), rank, world)
                 for b0 in range(lo, hi, a.BATCH_SIZE):
+                    e = span("predict_streamed")             # H2D chunks pipelined under the launches: one stage
                     out, xin, tgt = feeder.predict_streamed(model, b0, min(hi, b0 + a.BATCH_SIZE), chunk=a.STREAM_CHUNK)
+                    done(e)
                     yield xin, tgt, out, None
 
         if delay is not None and not is_dd:
             assert feeder.max_delay > 0, "--ADD_DELAY needs delay trajectories (stereo dataset or side-cars)"
         for xin, tgt, out, dt in batches():
             if delay is not None and not is_dd:                                   # :355-364 (`ADD_DELAY and MODEL == "GRU"`)
+                e = span("apply_delay")
                 out = ntm_amd.harness.apply_delay(delay, dt * fs, out)
+                done(e)
             n = xin.shape[-1] - init_len
             for key, fn in (("ESR", esr_sums), ("DCPreESR", esr_dcpre_sums)):
+                e = span(key)
                 s = fn(out, tgt, skip=init_len)
                 per[key].append((s[:, 0] / n) / (s[:, 1] / n + ESR_EPS))
+                done(e)
             if with_stft:
+                e = span("MultiSTFT")
                 per["MultiSTFT"].append(mrstft.per_segment(out, tgt, skip=init_len))
+                done(e)
         # every rank issues the SAME collectives whatever its shard holds (a rank with no segments -- more ranks than
         # segments -- reduces empty tensors): the key set depends on the global segment length only
         if not with_stft:
@@ -289,6 +339,8 @@ def compute_loss(a, feeder, model, names, delay, is_dd, init_len, rank, world, s
                for k, v in per.items()}
         n_seg = res['ESR']['segments']
         results = {k: v["mean_segment_loss"] for k, v in res.items()}
+        if stages is not None:                         # (reduce_loss_sums fetched the scalars: the device is idle here)
+            stages.host["loss_loop_s"] = time.perf_counter() - t_loop
         if rank == 0 and not a.NO_CACHE:
             try:                                   # a cache that cannot be written must never cost the printed results
                 os.makedirs(save_path, exist_ok=True)
