@@ -245,7 +245,7 @@ def measure_workload(workload, B, T, steps, warmup, check, dev, threads=1, delay
                 import glob                      # the taps come back from beyond L2)
                 why = None
                 if live:                         # two rocprofv3 --pmc child passes of `bench.py --workload diffdel`, in this run
-                    roof["traffic"], why = live_traffic(r"gru_mfma2_kernel<true, false, 0, 0, 16, true, false>",
+                    roof["traffic"], why = live_traffic(r"gru_mfma2_kernel<true, false, 0, 0, 16, true, false, false>",
                                                         ["--workload", "diffdel", "--batch", str(B), "--samples", str(T)])
                     roof["traffic_source"] = why
                 files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic_diffdel_fused*.json")))
@@ -938,7 +938,7 @@ def main():
     many = (B + 15) // 16 > torch.cuda.get_device_properties(local).multi_processor_count      # launch_gru_mfma2: YPN 4 / 16
     if T == 65536 and B > 1024 and a.variant in ("auto", "mfma2") and a.traffic != "off":
         profiled = any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
-        rx = r"gru_mfma2_kernel<true, false, 0, 0, " + ("4" if many else "16") + ", false, " + ("true>" if fused_esr else "false>")
+        rx = r"gru_mfma2_kernel<true, false, 0, 0, " + ("4" if many else "16") + ", false, " + ("true, false>" if fused_esr else "false, false>")
         if a.traffic == "live" or (a.traffic == "auto" and not profiled):     # never a profiler inside a profiler
             traffic, traffic_source = live_traffic(rx, ["--esr", a.esr, "--variant", a.variant, "--batch", str(B),
                                                         "--samples", str(a.samples)])

@@ -32,7 +32,7 @@ extern "C" {
 #define NTM_EHIP (-2)    /* HIP runtime error (launch failed, no device)               */
 #define NTM_EDELAY (-3)  /* reserved for host-side delay-range checks                  */
 
-#define NTM_ABI_VERSION 7 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag.  3: the TCN scratch is padded (ntm_tcn_scratch_floats grew), dilation / length limits.  4: ntm_diffdel_gru_forward is ONE fused launch where the matrix-pipe kernel runs (+ ntm_diffdel_gru_forward_ex).  5: ntm_gru_forward_esr, ntm_diffdel_gru_forward_esr.  6: ntm_tcn_forward works through the batch in stream chunks, ntm_tcn_scratch_floats is bounded (<= 2.0e9 floats + padding for any B), ntm_tcn_chunk_streams; DiffDelGRU warm-up calls always take the two-pass form.  7: ntm_loss_scalars (+ include/ntm_rccl.h, libntm_rccl.so) */
+#define NTM_ABI_VERSION 8 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag.  3: the TCN scratch is padded (ntm_tcn_scratch_floats grew), dilation / length limits.  4: ntm_diffdel_gru_forward is ONE fused launch where the matrix-pipe kernel runs (+ ntm_diffdel_gru_forward_ex).  5: ntm_gru_forward_esr, ntm_diffdel_gru_forward_esr.  6: ntm_tcn_forward works through the batch in stream chunks, ntm_tcn_scratch_floats is bounded (<= 2.0e9 floats + padding for any B), ntm_tcn_chunk_streams; DiffDelGRU warm-up calls always take the two-pass form.  7: ntm_loss_scalars (+ include/ntm_rccl.h, libntm_rccl.so).  8: any hidden size in [1, NTM_MAX_HIDDEN]; ntm_gru_forward_losses (ESR + DCPreESR sums in the recurrent launch) */
 
 #define NTM_HIDDEN 64 /* hidden size of every shipped checkpoint (HS[64]): matrix-pipe and low-latency kernels.
                          Every other H in [1, NTM_MAX_HIDDEN] (the reference's `--HIDDEN_SIZE` is a free integer,
@@ -103,6 +103,24 @@ int ntm_gru_forward_esr(const float *w_ih, const float *w_hh, const float *b_ih,
                         const float *w_o, const float *b_o, int H, const float *x, float *y,
                         int64_t B, int64_t T, int64_t x_stride_b, int64_t y_stride_b, float *h_state,
                         const float *target, int64_t skip, double *esr_out, void *stream);
+
+/*
+ * RNN.forward + BOTH time-domain entries of the loss dict in ONE call: replaces
+ *     output = model(input)  ...  for key in loss_fcns: loss_fcns[key](output[..., INIT_LEN:], target[..., INIT_LEN:])
+ * (code/test-model.py:250-252,346,386-388) for the ESR and the DCPreESR entries.  Arguments as ntm_gru_forward_esr, then the
+ * pole dcpre_R of the DC blocker (0.995 upstream) and dcpre_out [B,2] fp64 (device), the sums of ntm_esr_dcpre_sums:
+ *     dcpre_out[2b] = sum f(target - y)^2,   dcpre_out[2b+1] = sum f(target)^2,   f = (1 - z^-1)/(1 - R z^-1) from zero
+ * state at sample `skip`.  Where the matrix-pipe kernel runs (H = 64, B > NTM_GRU_LAT_MAX_B, skip a multiple of 4) both pairs
+ * of sums come out of that launch: the one-pole filter is a 16-lane scan inside the y-tile flush (the streaming pass reads
+ * y and target again, 2 GB at 4096 x 65 536); elsewhere the forward launch is followed by the two streaming passes.  The fp32
+ * filter is evaluated in scan order there and in the streaming kernel's order elsewhere: the two agree with each other and
+ * with the sequential recursion to ~1e-6 relative in the sums (not bit for bit).
+ */
+int ntm_gru_forward_losses(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                           const float *w_o, const float *b_o, int H, const float *x, float *y,
+                           int64_t B, int64_t T, int64_t x_stride_b, int64_t y_stride_b, float *h_state,
+                           const float *target, int64_t skip, double *esr_out, float dcpre_R,
+                           double *dcpre_out, void *stream);
 
 /*
  * Replaces TimeVaryingDelayLine.forward(x, dt, warmup), code/model.py:269-320.

@@ -25,6 +25,7 @@ _SIGNATURES = {
     "ntm_gru_forward": (_int, [_vp] * 6 + [_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp]),
     "ntm_gru_forward_ex": (_int, [_vp] * 6 + [_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _int, _vp]),
     "ntm_gru_forward_esr": (_int, [_vp] * 6 + [_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp]),
+    "ntm_gru_forward_losses": (_int, [_vp] * 6 + [_int, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, ctypes.c_float, _vp, _vp]),
     "ntm_delay_forward": (_int, [_vp, _vp, _vp, _i64, _i64, _vp, _int, _int, _vp, _vp]),
     "ntm_diffdel_gru_forward": (_int, [_vp] * 5 + [_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _int,
                                                    _vp, _vp]),
@@ -64,7 +65,7 @@ LAB_VARIANTS = ("mfma", "valu", "mfma3", "mfma4")
 
 _lib = None
 _lab = None
-ABI_VERSION = 7          # include/ntm.h NTM_ABI_VERSION this binding was written against
+ABI_VERSION = 8          # include/ntm.h NTM_ABI_VERSION this binding was written against
 HIDDEN_SIZES = (8, 16, 32, 64)      # sizes with a kernel of their own; every H in [1, MAX_HIDDEN] runs (include/ntm.h)
 MAX_HIDDEN = 1024
 NTM_DIFFDEL_AUTO, NTM_DIFFDEL_TWO_PASS, NTM_DIFFDEL_FUSED = 0, 1, 2

@@ -158,10 +158,18 @@ __device__ __forceinline__ f32x4 pack_hl(const f16x4 hi, const f16x4 lo)
 //   As a separate pass on a side stream the 2 GB ESR kernel overlapped the NEXT step's launch and cost that launch
 //   0.37 ms -- its vector instructions take issue slots and datapath from the one wave per SIMD that feeds the matrix
 //   pipe; here it is ~25 instructions per thread and tile.
+// DCP = true (with ESR, GRU only): the DCPreESR entry of the loss dict (code/test-model.py:252) in the same flush.  Both
+//   signals e = t - y and t pass H(z) = (1 - z^-1)/(1 - R z^-1) from zero state at esr_skip and sum f(e)^2, sum f(t)^2 are
+//   accumulated per stream (ntm_esr_dcpre_sums' definition).  The 16 threads that flush a stream's tile are one DPP row:
+//   each runs its 4 samples from zero state, a 4-step row_shr scan with the constant ratios R^4, R^8, R^16, R^32 gives
+//   every lane the state entering it, lane 15's end state and last input are broadcast to the row (row_newbcast:15) for
+//   the next tile -- no LDS traffic (the step barrier's hand-counted lgkmcnt stays valid), ~70 vector instructions per
+//   thread and tile.  fp32 filter (scan order instead of the streaming kernel's; both agree with the sequential
+//   recursion of the oracle to ~1e-6 relative in the sums), fp64 sums.
 #ifndef NTM_TANH_FORM
 #define NTM_TANH_FORM 0
 #endif
-template <bool PRESCALE, bool STAMP, int ABL = 0, int ENGINE = 0, int YPN = 16, bool FUSE = false, bool ESR = false>
+template <bool PRESCALE, bool STAMP, int ABL = 0, int ENGINE = 0, int YPN = 16, bool FUSE = false, bool ESR = false, bool DCP = false>
 __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 {
     using namespace m2;
@@ -305,6 +313,69 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         esr_tg = *(const f32x4y *)(esr_row + tile * TT);
         esr_tile = tile;
     };
+    // ---- DCP: the one-pole filter state of the stream's row (row-uniform), the fp64 sums of this thread's columns ----
+    static_assert(!DCP || (ESR && !FUSE), "the DCPreESR sums ride in the GRU kernel's ESR flush");
+    double dcp_e = 0.0, dcp_t = 0.0;
+    float dcp_ce = 0.0f, dcp_ct = 0.0f;                      // filter outputs at the last sample of the previous tile
+    float dcp_le = 0.0f, dcp_lt = 0.0f;                      // filter inputs there
+    const float dR1 = a.dcp_R, dR2 = dR1 * dR1, dR3 = dR2 * dR1, dR4 = dR2 * dR2, dR8 = dR4 * dR4, dR16 = dR8 * dR8, dR32 = dR16 * dR16;
+    float dRc = 1.0f;                                        // R^(4 c): decay from the tile's start to this lane's first sample
+    if constexpr (DCP) {
+        for (int i = 0; i < (tid & 15); ++i) dRc *= dR4;
+    }
+    (void)dcp_e; (void)dcp_t; (void)dcp_ce; (void)dcp_ct; (void)dcp_le; (void)dcp_lt; (void)dR3; (void)dR32; (void)dRc;
+    f32x4 esr_used = {0.0f, 0.0f, 0.0f, 0.0f};               // the target values the last esr_accumulate saw
+    (void)esr_used;
+    auto dpp_shr = [](float x, auto n_c) {                   // lane c of a 16-lane row <- lane c - N (0 where there is none)
+        constexpr int N = decltype(n_c)::value;
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x110 + N, 0xf, 0xf, false));
+    };
+    auto dpp_last = [](float x) {                            // every lane of a row <- lane 15 of the row (row_newbcast:15)
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x15F, 0xf, 0xf, false));
+    };
+    // one signal of one tile: u[0..3] = this thread's 4 filter inputs (zero outside [skip, T)), `last` / `state` the row's
+    // carried input / output; -> the 4 filter outputs in u, carries moved on
+    auto dcp_filter = [&](float (&u)[4], float &last, float &state) {
+        using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>;
+        const float prev = (tid & 15) ? dpp_shr(u[3], I1{}) : last;
+        const float f0 = u[0] - prev;
+        const float f1 = __builtin_fmaf(dR1, f0, u[1] - u[0]);
+        const float f2 = __builtin_fmaf(dR1, f1, u[2] - u[1]);
+        const float f3 = __builtin_fmaf(dR1, f2, u[3] - u[2]);
+        last = dpp_last(u[3]);
+        float b = f3;                                         // inclusive scan of the lanes' end values, ratio R^4 per lane
+        b = __builtin_fmaf(dR4, dpp_shr(b, I1{}), b);
+        b = __builtin_fmaf(dR8, dpp_shr(b, I2{}), b);
+        b = __builtin_fmaf(dR16, dpp_shr(b, I4{}), b);
+        b = __builtin_fmaf(dR32, dpp_shr(b, I8{}), b);
+        const float in = __builtin_fmaf(dRc, state, dpp_shr(b, I1{}));      // state entering this lane's first sample
+        u[0] = __builtin_fmaf(dR1, in, f0);
+        u[1] = __builtin_fmaf(dR2, in, f1);
+        u[2] = __builtin_fmaf(dR3, in, f2);
+        u[3] = __builtin_fmaf(dR4, in, f3);
+        state = dpp_last(u[3]);
+    };
+    auto dcp_accumulate = [&](int64_t tile, const f32x4 v, const f32x4 tg, auto whole_c) {
+        constexpr bool WHOLE = decltype(whole_c)::value;
+        const int64_t gt = tile * TT + 4 * (tid & 15);
+        float ue[4], ut[4];
+        bool in[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            in[c] = WHOLE ? gt >= a.esr_skip : (gt + c >= a.esr_skip && gt + c < T);
+            ut[c] = in[c] ? tg[c] : 0.0f;
+            ue[c] = in[c] ? tg[c] - v[c] : 0.0f;
+        }
+        dcp_filter(ue, dcp_le, dcp_ce);
+        dcp_filter(ut, dcp_lt, dcp_ct);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (!WHOLE && !in[c]) continue;                   // (whole tiles ahead of esr_skip add exact zeros)
+            dcp_e += (double)ue[c] * (double)ue[c];
+            dcp_t += (double)ut[c] * (double)ut[c];
+        }
+    };
     auto esr_accumulate = [&](int64_t tile, const f32x4 v, auto whole_c) {
         constexpr bool WHOLE = decltype(whole_c)::value;
         const int64_t gt = tile * TT + 4 * (tid & 15);
@@ -313,6 +384,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 #pragma unroll
             for (int c = 0; c < 4; ++c) tg[c] = gt + c < T ? esr_row[tile * TT + c] : 0.0f;
         }
+        if constexpr (DCP) dcp_accumulate(tile, v, tg, whole_c);
         if (WHOLE ? gt >= a.esr_skip : true) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -826,6 +898,17 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
             a.esr_out[(s0 + (tid >> 4)) * 2 + 0] = esr_e;
             a.esr_out[(s0 + (tid >> 4)) * 2 + 1] = esr_t;
         }
+        if constexpr (DCP) {
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                dcp_e += __shfl_xor(dcp_e, off, 16);
+                dcp_t += __shfl_xor(dcp_t, off, 16);
+            }
+            if (y_row_ok && (tid & 15) == 0) {
+                a.dcp_out[(s0 + (tid >> 4)) * 2 + 0] = dcp_e;
+                a.dcp_out[(s0 + (tid >> 4)) * 2 + 1] = dcp_t;
+            }
+        }
     }
 
     if (a.h_state && valid) {
@@ -879,6 +962,9 @@ hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream)
 #endif
     if (a.tgt) {        // predict + ESR sums in one launch (exact fp32 engine)
         if (!a.esr_out || a.engine || (a.esr_skip & 3) || a.esr_skip < 0) return hipErrorInvalidValue;
+        if (a.dcp_out)  // ... + the DCPreESR sums
+            return many ? NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 4, false, true, true>), smem4)
+                        : NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 16, false, true, true>), smem16);
         return many ? NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 4, false, true>), smem4)
                     : NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 16, false, true>), smem16);
     }

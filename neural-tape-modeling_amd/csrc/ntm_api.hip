@@ -111,22 +111,27 @@ int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, 
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_gru_forward");
 }
 
-int ntm_gru_forward_esr(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *w_o,
-                        const float *b_o, int H, const float *x, float *y, int64_t B, int64_t T, int64_t x_stride_b,
-                        int64_t y_stride_b, float *h_state, const float *target, int64_t skip, double *esr_out, void *stream)
+// ntm_gru_forward_esr (dcp_out == NULL) and ntm_gru_forward_losses share this body
+static int gru_losses_impl(const char *who, const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *w_o,
+                           const float *b_o, int H, const float *x, float *y, int64_t B, int64_t T, int64_t x_stride_b,
+                           int64_t y_stride_b, float *h_state, const float *target, int64_t skip, double *esr_out, float R,
+                           double *dcp_out, void *stream)
 {
-    // every argument is checked BEFORE anything is enqueued: an NTM_EINVAL leaves y, h_state and esr_out untouched
-    if (H < 1 || H > NTM_MAX_HIDDEN) return fail(NTM_EINVAL, "ntm_gru_forward_esr: hidden size must lie in [1, 1024]");
-    if (B < 0 || T < 0 || skip < 0 || skip > T) return fail(NTM_EINVAL, "ntm_gru_forward_esr: bad size");
+    const std::string w(who);
+    // every argument is checked BEFORE anything is enqueued: an NTM_EINVAL leaves y, h_state and the sums untouched
+    if (H < 1 || H > NTM_MAX_HIDDEN) return fail(NTM_EINVAL, w + ": hidden size must lie in [1, 1024]");
+    if (B < 0 || T < 0 || skip < 0 || skip > T) return fail(NTM_EINVAL, w + ": bad size");
+    if (dcp_out && !(R >= 0.0f && R < 1.0f)) return fail(NTM_EINVAL, w + ": R must be in [0,1)");
     if (B == 0) return NTM_OK;
-    if (!target || !esr_out) return fail(NTM_EINVAL, "ntm_gru_forward_esr: null pointer");
+    if (!target || !esr_out) return fail(NTM_EINVAL, w + ": null pointer");
     if (T == 0) {                                // no samples: the sums are zero
         hipError_t ez = hipMemsetAsync(esr_out, 0, (size_t)B * 2 * sizeof(double), (hipStream_t)stream);
-        return ez == hipSuccess ? NTM_OK : hip_fail(ez, "ntm_gru_forward_esr");
+        if (ez == hipSuccess && dcp_out) ez = hipMemsetAsync(dcp_out, 0, (size_t)B * 2 * sizeof(double), (hipStream_t)stream);
+        return ez == hipSuccess ? NTM_OK : hip_fail(ez, who);
     }
-    if (!w_ih || !w_hh || !b_ih || !b_hh || !w_o || !x || !y) return fail(NTM_EINVAL, "ntm_gru_forward_esr: null pointer");
-    if (x_stride_b < T || y_stride_b < T) return fail(NTM_EINVAL, "ntm_gru_forward_esr: stride < T");
-    if (target == y) return fail(NTM_EINVAL, "ntm_gru_forward_esr: target must not alias y");
+    if (!w_ih || !w_hh || !b_ih || !b_hh || !w_o || !x || !y) return fail(NTM_EINVAL, w + ": null pointer");
+    if (x_stride_b < T || y_stride_b < T) return fail(NTM_EINVAL, w + ": stride < T");
+    if (target == y) return fail(NTM_EINVAL, w + ": target must not alias y");
     // streams the matrix-pipe kernel takes (as ntm_gru_forward's NTM_GRU_AUTO decides): there the sums ride in the launch
     int64_t fused = 0;
     if (H == NTM_HIDDEN && B > NTM_GRU_LAT_MAX_B && (skip & 3) == 0) {
@@ -135,24 +140,47 @@ int ntm_gru_forward_esr(const float *w_ih, const float *w_hh, const float *b_ih,
         fused = (full > 0 && rem > 0 && rem <= NTM_GRU_LAT_MAX_B) ? full : B;
     }
     if (fused < B && y_stride_b != T)
-        return fail(NTM_EINVAL, "ntm_gru_forward_esr: the streaming ESR pass (streams outside the matrix-pipe launch) needs contiguous y rows (stride T)");
+        return fail(NTM_EINVAL, w + ": the streaming loss passes (streams outside the matrix-pipe launch) need contiguous y rows (stride T)");
     if (fused > 0) {
         ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, fused, T, x_stride_b, y_stride_b, nullptr, 0, 0};
         a.tgt = target;
         a.esr_out = esr_out;
         a.esr_skip = skip;
+        a.dcp_out = dcp_out;
+        a.dcp_R = R;
         hipError_t e = ntm::launch_gru_mfma2(a, (hipStream_t)stream);
-        if (e != hipSuccess) return hip_fail(e, "ntm_gru_forward_esr");
+        if (e != hipSuccess) return hip_fail(e, who);
     }
-    if (fused < B) {            // the rest: the forward launch the library would pick, then the streaming ESR pass (one row per stream)
+    if (fused < B) {            // the rest: the forward launch the library would pick, then the streaming passes (one row per stream)
         const int64_t r = B - fused;
         int rc = ntm_gru_forward(w_ih, w_hh, b_ih, b_hh, w_o, b_o, H, x + fused * x_stride_b, y + fused * y_stride_b, r, T,
                                  x_stride_b, y_stride_b, h_state ? h_state + fused * H : nullptr, stream);
         if (rc != NTM_OK) return rc;
         hipError_t e = ntm::launch_esr(y + fused * T, target + fused * T, r, T, skip, 1, esr_out + 2 * fused, (hipStream_t)stream);
-        if (e != hipSuccess) return hip_fail(e, "ntm_gru_forward_esr");
+        if (e == hipSuccess && dcp_out)
+            e = ntm::launch_esr_dcpre(y + fused * T, target + fused * T, r, T, skip, R, dcp_out + 2 * fused, (hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, who);
     }
     return NTM_OK;
+}
+
+int ntm_gru_forward_esr(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *w_o,
+                        const float *b_o, int H, const float *x, float *y, int64_t B, int64_t T, int64_t x_stride_b,
+                        int64_t y_stride_b, float *h_state, const float *target, int64_t skip, double *esr_out, void *stream)
+{
+    return gru_losses_impl("ntm_gru_forward_esr", w_ih, w_hh, b_ih, b_hh, w_o, b_o, H, x, y, B, T, x_stride_b, y_stride_b, h_state, target,
+                           skip, esr_out, 0.0f, nullptr, stream);
+}
+
+int ntm_gru_forward_losses(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *w_o,
+                           const float *b_o, int H, const float *x, float *y, int64_t B, int64_t T, int64_t x_stride_b,
+                           int64_t y_stride_b, float *h_state, const float *target, int64_t skip, double *esr_out, float dcpre_R,
+                           double *dcpre_out, void *stream)
+{
+    if (!dcpre_out) return fail(NTM_EINVAL, "ntm_gru_forward_losses: null pointer");
+    if (dcpre_out == esr_out) return fail(NTM_EINVAL, "ntm_gru_forward_losses: esr_out and dcpre_out must be distinct");
+    return gru_losses_impl("ntm_gru_forward_losses", w_ih, w_hh, b_ih, b_hh, w_o, b_o, H, x, y, B, T, x_stride_b, y_stride_b, h_state,
+                           target, skip, esr_out, dcpre_R, dcpre_out, stream);
 }
 
 int ntm_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *w_o,

@@ -45,6 +45,8 @@ struct GruArgs {
     const float *tgt = nullptr;     // target [B,T], contiguous
     double *esr_out = nullptr;      // [B,2] fp64
     int64_t esr_skip = 0;           // multiple of 4
+    double *dcp_out = nullptr;      // gru_mfma2_kernel<ESR, DCP>: [B,2] fp64 DC-pre-emphasised sums (non-null selects DCP)
+    float dcp_R = 0.995f;           // pole of the DC blocker
     int H = 64;                     // hidden size as the caller's tensors have it (gru_small.hip: any size but 64; the
                                     // matrix-pipe / low-latency kernels are compiled for kH)
 };

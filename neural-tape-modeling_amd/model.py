@@ -151,6 +151,23 @@ class _GRUHead(torch.nn.Module):
         self.hidden = h
         return y, sums
 
+    def _gru_losses(self, xbt, tbt, skip, R):
+        """As _gru_esr, plus the DC-pre-emphasised sums (B,2) fp64, through ONE C-ABI call (ntm_gru_forward_losses): where the
+        matrix-pipe kernel runs BOTH pairs of sums ride in the recurrent launch."""
+        B, T = xbt.shape
+        _require_hip(self.GRU.weight_hh_l0, "model parameters (call .to('cuda'))")
+        h = self._hidden_for(B, xbt.device)
+        y = torch.empty_like(xbt)
+        sums = torch.empty(B, 2, device=xbt.device, dtype=torch.float64)
+        dsums = torch.empty(B, 2, device=xbt.device, dtype=torch.float64)
+        g, o = self.GRU, self.output
+        rc = _lib.lib().ntm_gru_forward_losses(ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0),
+                                               ptr(o.weight), ptr(o.bias), self.hidden_size, ptr(xbt), ptr(y), B, T, T, T, ptr(h),
+                                               ptr(tbt), int(skip), ptr(sums), float(R), ptr(dsums), _lib.current_stream())
+        _lib.check(rc, "ntm_gru_forward_losses")
+        self.hidden = h
+        return y, sums, dsums
+
     @torch.no_grad()
     def forward_into(self, x2d, y2d):
         """Stateful forward on ROW-STRIDED [B,Tc] fp32 views (unit stride along time), e.g. the time chunk
@@ -241,6 +258,35 @@ class RNN(_GRUHead):
         if B != 1:
             self.hidden = self.hidden.expand(1, B, self.hidden_size).contiguous()
         return self.forward_esr(input, target, skip)
+
+    @torch.no_grad()
+    def forward_losses(self, x, target, skip=0, R=None):
+        """forward(x) AND both time-domain entries of the loss dict against `target` over samples [skip, T) -- `output =
+        model(input)` followed by the ESR and DCPreESR losses (code/test-model.py:250-252,346,386-388) -- in one call:
+        (y (N,1,T), ESR sums (N,2) fp64 = [sum (t-y)^2, sum t^2], DCPreESR sums (N,2) fp64 = the same of the DC-blocked
+        signals): the numbers of `esr_sums` / `esr_dcpre_sums` on `self(x)` (ESR up to fp64 summation order, DCPreESR up to
+        the fp32 evaluation order of the one-pole filter, ~1e-6 relative).  With `kernel_variant == "auto"` and no skip
+        connection it is ONE launch where the matrix-pipe kernel runs."""
+        R = DC_PRE_R if R is None else R
+        xbt = _as_bt(x, "RNN.forward_losses")
+        tbt = _as_bt(target, "RNN.forward_losses")
+        if tbt.shape != xbt.shape:
+            raise RuntimeError(f"shape mismatch: x {tuple(x.shape)} vs target {tuple(target.shape)}")
+        if self.kernel_variant != "auto" or self.skip:
+            y = self.forward(x)
+            return y, esr_sums(y, target, skip), esr_dcpre_sums(y, target, skip, R)
+        y, sums, dsums = self._gru_losses(xbt, tbt, skip, R)
+        return y.view(xbt.shape[0], 1, xbt.shape[1]), sums, dsums
+
+    @torch.no_grad()
+    def predict_losses(self, input, target, skip=0, R=None):
+        """predict(input) + the ESR and DCPreESR sums against `target` over [skip, T)."""
+        B = input.shape[0]
+        self.initialize_hidden()
+        self.warm_start()
+        if B != 1:
+            self.hidden = self.hidden.expand(1, B, self.hidden_size).contiguous()
+        return self.forward_losses(input, target, skip, R)
 
     @torch.no_grad()
     def predict(self, input, segment_length=None):

@@ -245,3 +245,87 @@ def test_bench_cli_workload_stage_times_and_cpu_port():
     for k in ("ESR", "DCPreESR", "MultiSTFT"):           # same command, same two segments: the CPU port's losses
         assert abs(r["losses"][k] / cpu["losses"][k] - 1) < 2e-3, (k, r["losses"], cpu["losses"])
     assert "scripts/test-model-loss.sh" in r["reference_command"] and not os.path.exists("/tmp/ntm_cli_leftover")
+
+
+# ----------------------------------------------------------------------------- DCPreESR sums out of the recurrent launch
+W_G = "GRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE]_BEST"
+
+
+@pytest.mark.parametrize("B,T,skip", [(1040, 64, 0), (1040, 300, 64), (1040, 4136, 1024), (1040, 1000, 4), (1300, 777, 128),
+                                      (4112, 500, 64), (4200, 700, 256), (1040, 300, 2), (700, 300, 64), (1040, 5, 0), (1040, 129, 128)])
+def test_forward_losses_esr_and_dcpre_in_one_launch(ntm, B, T, skip):
+    """RNN.predict_losses (ntm_gru_forward_losses): y bit-identical to predict(), the ESR sums bit-identical to
+    predict_esr's, the DCPreESR sums against the streaming kernel on the same output (fp32 filter in another evaluation
+    order: 2e-6 rel) and against the oracle's sequential recursion (2e-5 rel, the streaming kernel's own bar).  Shapes: one /
+    several / ragged 64-sample tiles, skip inside a tile and beyond the first tile, 4112 = whole device rounds + a remainder
+    on the low-latency kernel, 4200 > 4096 (three workgroups per CU, YPN = 4), skip = 2 and B = 700 (no fused launch: forward
+    + the two streaming passes)."""
+    rng = np.random.default_rng(B + T + skip)
+    x = rng.uniform(-0.5, 0.5, (B, T)).astype(np.float32)
+    t = (0.6 * np.tanh(1.7 * x) + 0.05 + 0.01 * rng.standard_normal((B, T))).astype(np.float32)     # a DC offset for the blocker
+    xd, td = dev(x).unsqueeze(1), dev(t).unsqueeze(1)
+    m = ntm.harness.build_model(W_G)
+    y, s, d = m.predict_losses(xd, td, skip=skip)
+    h = m.hidden.clone()
+    y0 = m.predict(xd)
+    assert torch.equal(y, y0) and torch.equal(m.hidden, h)
+    y1, s1 = m.predict_esr(xd, td, skip=skip)
+    assert torch.equal(y1, y0) and torch.equal(s1, s)
+    d_stream = ntm.esr_dcpre_sums(y0, td, skip).cpu().numpy()
+    got = d.cpu().numpy()
+    assert np.isfinite(got).all()
+    scale = np.maximum(np.abs(d_stream), 1e-30)
+    assert (np.abs(got - d_stream) / scale).max() < 2e-6 or T - skip <= 1, (np.abs(got - d_stream) / scale).max()
+    rows = [0, 15, 16, B // 2, B - 1]
+    want = oracle.esr_dcpre_sums(y0[rows, 0].cpu().numpy(), t[rows], skip)
+    assert np.allclose(got[rows], want, rtol=2e-5, atol=1e-12)
+    # another pole, and R = 0 (a plain first difference)
+    for R in (0.9, 0.0):
+        _, _, dr = m.predict_losses(xd, td, skip=skip, R=R)
+        assert np.allclose(dr[rows].cpu().numpy(), oracle.esr_dcpre_sums(y0[rows, 0].cpu().numpy(), t[rows], skip, R), rtol=2e-5, atol=1e-12)
+
+
+def test_forward_losses_on_a_ten_second_segment_and_through_the_c_abi(ntm):
+    """441 000 samples (6890 whole tiles + 40 samples: the ragged last tile), INIT_LEN 2048 as the toy data gives; then the C
+    entry point's argument checks (nothing enqueued on NTM_EINVAL)."""
+    rng = np.random.default_rng(9)
+    B, T, skip = 1040, 441000, 2048
+    x1 = (0.4 * np.sin(np.arange(T) * 0.03) * (0.6 + 0.4 * np.sin(np.arange(T) * 1e-4)) + 0.02 * rng.standard_normal(T)).astype(np.float32)
+    t1 = (0.5 * np.tanh(2.0 * x1) + 0.02).astype(np.float32)
+    xd = dev(np.broadcast_to(x1, (B, T)).copy()).unsqueeze(1)
+    td = dev(np.broadcast_to(t1, (B, T)).copy()).unsqueeze(1)
+    m = ntm.harness.build_model(W_G)
+    y, s, d = m.predict_losses(xd, td, skip=skip)
+    assert torch.equal(d[0], d[519]) and torch.equal(d[0], d[B - 1]) and torch.equal(s[0], s[B - 1])
+    want = oracle.esr_dcpre_sums(y[:1, 0].cpu().numpy(), t1[None], skip)
+    assert np.allclose(d[:1].cpu().numpy(), want, rtol=2e-5)
+    L = ntm._lib.lib()
+    one, two, three = (ctypes_ptr(v) for v in (16, 32, 48))
+    assert L.ntm_gru_forward_losses(one, one, one, one, one, None, 64, one, two, 4, 100, 100, 100, None, three, 0, one, 0.995, None, None) == -1
+    assert L.ntm_gru_forward_losses(one, one, one, one, one, None, 64, one, two, 4, 100, 100, 100, None, three, 0, one, 1.5, two, None) == -1
+    assert b"R must be in [0,1)" in L.ntm_last_error()
+    assert L.ntm_gru_forward_losses(one, one, one, one, one, None, 64, one, two, 4, 100, 100, 100, None, three, 0, one, 0.995, one, None) == -1
+    assert b"distinct" in L.ntm_last_error()
+    assert L.ntm_gru_forward_losses(one, one, one, one, one, None, 64, one, two, 0, 100, 100, 100, None, three, 0, one, 0.995, two, None) == 0
+
+
+def ctypes_ptr(v):
+    import ctypes
+    return ctypes.c_void_p(v)
+
+
+def test_cli_fused_losses_path_matches_the_separate_passes(tmp_path, monkeypatch):
+    """tools/test_model.py with --STREAM_CHUNK 0 on a plain GRU evaluation issues predict + ESR + DCPreESR as one call
+    (RNN.predict_losses); same losses as the default streamed pipeline with its separate passes."""
+    from test_cli import _wow_dataset, cli_module
+    cli = cli_module("ntm_cli_r5b")
+    _wow_dataset(tmp_path, "Wow")
+    monkeypatch.chdir(tmp_path)
+    argv = ["--MODEL", "GRU", "--WEIGHTS", W_G, "--DATASET_DIR", str(tmp_path / "Wow"), "--SUBSET", "Test", "--NO_SHUFFLE",
+            "--SEGMENT_LENGTH", "12000", "--COMPUTE_LOSS", "--NO_EXAMPLE", "--NO_CACHE"]
+    prof_a, prof_b = {}, {}
+    a = cli.main(argv, profile=prof_a)
+    b = cli.main(argv + ["--STREAM_CHUNK", "0"], profile=prof_b)
+    assert "predict_streamed_ms" in prof_a and "ESR_ms" in prof_a and "DCPreESR_ms" in prof_a
+    assert "predict+ESR+DCPreESR_ms" in prof_b and "ESR_ms" not in prof_b and "DCPreESR_ms" not in prof_b and prof_b["h2d_ms"] > 0
+    assert abs(a["ESR"] / b["ESR"] - 1) < 1e-9 and abs(a["DCPreESR"] / b["DCPreESR"] - 1) < 1e-5 and abs(a["MultiSTFT"] / b["MultiSTFT"] - 1) < 1e-9

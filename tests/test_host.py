@@ -34,7 +34,7 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lab, s), f"libntm_lab.so does not export {s}"
         assert not hasattr(lib, s), f"the product library exports the laboratory symbol {s}"
     assert set(ntm_amd._lib._LAB_SIGNATURES) == set(lab_syms)
-    assert ntm_amd._lib.lib().ntm_abi_version() == 7 == ntm_amd._lib.ABI_VERSION
+    assert ntm_amd._lib.lib().ntm_abi_version() == 8 == ntm_amd._lib.ABI_VERSION
 
 
 def test_rccl_helper_library_loads_and_exports_its_header():

@@ -18,7 +18,7 @@ PYEOF
 timeout 900 $PY tools/nrow_rooflines.py -o "$OUT/${TAG}_nrow_rooflines.json" 2> "$OUT/${TAG}_nrow_rooflines.txt"; echo "nrow exit $?"; cat "$OUT/${TAG}_nrow_rooflines.txt"
 for B in 8192 16384 32768; do
     ALG=$((B * 65536 * 12))
-    timeout 900 bash tools/pmc_traffic.sh $TAG mfma2_esr_B$B 'gru_mfma2_kernel<true, false, 0, 0, 4, false, true>' $ALG bench.py --steps 3 --warmup 1 --batch $B --no-cpu-baseline --no-extra --other off --traffic off
+    timeout 900 bash tools/pmc_traffic.sh $TAG mfma2_esr_B$B 'gru_mfma2_kernel<true, false, 0, 0, 4, false, true, false>' $ALG bench.py --steps 3 --warmup 1 --batch $B --no-cpu-baseline --no-extra --other off --traffic off
 done
 bash tools/profile_all.sh $TAG gru diffdel tcn tape losses
 rm -rf "$OUT"/${TAG}_prof_* "$OUT"/${TAG}_pmc_*_FETCH_SIZE "$OUT"/${TAG}_pmc_*_WRITE_SIZE

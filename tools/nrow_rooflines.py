@@ -126,7 +126,7 @@ def main(argv):
     stft_mix = {int(re.search(r"ILi(\d+)ELi0E", k).group(1)): v
                 for k, v in hot_loop(os.path.join(CSRC, "stft_kernels.hip"), r"stft_sums_kernelILi\d+ELi0E").items()}
     out["static"] = {"tape_hmag_kernel (one sample of one wavefront = 64 streams)": tape_mix,
-                     "stft_sums_kernel<log2 n_fft, mode 0> (one frame PAIR of one wavefront)": {str(1 << k): v for k, v in sorted(stft_mix.items())}}
+                     "stft_sums_kernel<log2 n_fft, mode 0> (one frame PAIR of one wavefront: the y and the target frame of one hop position through ONE complex FFT)": {str(1 << k): v for k, v in sorted(stft_mix.items())}}
     meas = None if "--static-only" in argv else measure()
     table = []
     if meas:
@@ -157,13 +157,13 @@ def main(argv):
         rows = {}
         for key, m in meas["stft_sums"].items():
             n, frames, B, sec = m["n_fft"], m["frames"], m["B"], m["ms"] * 1e-3
-            pairs = (frames + 1) // 2
+            pairs = frames        # a "frame pair" = the y frame and the target frame of ONE hop position, packed as z = y + i t
             lg = n.bit_length() - 1
             alg = 5.0 * n * lg + 6.0 * n + 10.0 * (n // 2 + 1)     # complex FFT + window of two signals + |.|^2, sqrt, log, sums of two spectra
             mix = stft_mix[lg]
             ex = mix["flops_per_lane"] * 64.0
             issue = mix["issue_cycles"] * B * pairs / SIMDS / (CLOCK_GHZ * 1e9)
-            r = {"ms": m["ms"], "frame_pairs_per_stream": pairs,
+            r = {"ms": m["ms"], "frame_pairs_per_stream (= frames: y and target frame of a hop position)": pairs,
                  "algorithmic": {"flop_per_frame_pair": alg, "tflops": alg * B * pairs / sec / 1e12, "frac_of_fp32_peak": alg * B * pairs / sec / 1e12 / PEAK["f32"]},
                  "executed": {"flop_per_frame_pair": ex, "tflops": ex * B * pairs / sec / 1e12, "frac_of_fp32_peak": ex * B * pairs / sec / 1e12 / PEAK["f32"]},
                  "issue_bound": {"issue_cycles_per_frame_pair": mix["issue_cycles"], "seconds_if_every_simd_only_issued": issue, "frac": issue / sec,

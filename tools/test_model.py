@@ -265,7 +265,7 @@ def compute_loss(a, feeder, model, names, delay, is_dd, init_len, rank, world, s
     safe = [str(n).replace(os.sep, "_").replace("/", "_") for n in names]
     save_name = f"{safe}_DELAY[{a.ADD_DELAY}]_DEMODULATE[{a.DEMODULATE}]_NOISE[{a.ADD_NOISE}].npy"
     cached = os.path.join(save_path, save_name)
-    key = loss_cache_key(a, feeder, names, init_len)
+    cache_key = loss_cache_key(a, feeder, names, init_len)
     results = None
     if os.path.exists(cached) and not a.NO_CACHE:
         # every rank takes the same decision: it depends on the file and the arguments only
@@ -274,14 +274,15 @@ def compute_loss(a, feeder, model, names, delay, is_dd, init_len, rank, world, s
             blob = np.load(cached, allow_pickle=True).item()
         except Exception as e:
             blob, why = None, f"unreadable: {type(e).__name__}"
-        if isinstance(blob, dict) and blob.get("_key") == key:
+        if isinstance(blob, dict) and blob.get("_key") == cache_key:
             say(" Loading pre-computed!")
             results = {k: v for k, v in blob.items() if not k.startswith("_")}
             n_seg = blob.get("_segments", len(feeder))
         else:
             if isinstance(blob, dict):
-                old = blob.get("_key") or {}
-                why = "differs in " + ", ".join(sorted(k for k in set(old) | set(key) if old.get(k) != key.get(k))) if old else "no argument record"
+                old = blob.get("_key")
+                why = ("differs in " + ", ".join(sorted(k for k in set(old) | set(cache_key) if old.get(k) != cache_key.get(k)))
+                       if isinstance(old, dict) else "no argument record")
             say(f" (cached results belong to other arguments [{why}]: recomputing)", end="")
     if results is None:
         say(" Starting analysis...")
@@ -294,17 +295,26 @@ def compute_loss(a, feeder, model, names, delay, is_dd, init_len, rank, world, s
         done = lambda e: e.record() if e is not None else None                       # noqa: E731
         t_loop = time.perf_counter()
 
+        # plain GRU on whole-batch copies (--STREAM_CHUNK 0): predict + the ESR and DCPreESR sums in ONE launch where the
+        # matrix-pipe kernel runs (RNN.predict_losses / ntm_gru_forward_losses); needs INIT_LEN to be a multiple of 4
+        fused_losses = (not is_dd and delay is None and not a.DEMODULATE and a.STREAM_CHUNK <= 0 and a.KERNEL == "auto"
+                        and init_len % 4 == 0)
+
         def batches():
             if a.DEMODULATE or a.ADD_DELAY or a.STREAM_CHUNK <= 0:
                 for xin, tgt, dt, _ in feeder.batches(a.BATCH_SIZE, "cuda", rank, world, timing=None if stages is None else stages.h2d):
-                    e = span("predict")
+                    pre = None
+                    e = span("predict+ESR+DCPreESR" if fused_losses else "predict")
                     if is_dd:
                         assert dt is not None, "DiffDelGRU needs trajectory_<id>_*.npy side-cars"
                         out, _ = model.predict(xin, dt * fs)
+                    elif fused_losses:
+                        out, s_esr, s_dc = model.predict_losses(xin, tgt, skip=init_len)
+                        pre = {"ESR": s_esr, "DCPreESR": s_dc}
                     else:
                         out = model.predict(xin)
                     done(e)
-                    yield xin, tgt, out, dt
+                    yield xin, tgt, out, dt, pre
             else:
                 # predict straight from the feeder's pinned files, H2D copies pipelined along time under the launches
                 lo, hi = D.shard_range(len(feeder), rank, world)
@@ -312,17 +322,21 @@ def compute_loss(a, feeder, model, names, delay, is_dd, init_len, rank, world, s
                     e = span("predict_streamed")             # H2D chunks pipelined under the launches: one stage
                     out, xin, tgt = feeder.predict_streamed(model, b0, min(hi, b0 + a.BATCH_SIZE), chunk=a.STREAM_CHUNK)
                     done(e)
-                    yield xin, tgt, out, None
+                    yield xin, tgt, out, None, None
 
         if delay is not None and not is_dd:
             assert feeder.max_delay > 0, "--ADD_DELAY needs delay trajectories (stereo dataset or side-cars)"
-        for xin, tgt, out, dt in batches():
+        for xin, tgt, out, dt, pre in batches():
             if delay is not None and not is_dd:                                   # :355-364 (`ADD_DELAY and MODEL == "GRU"`)
                 e = span("apply_delay")
                 out = ntm_amd.harness.apply_delay(delay, dt * fs, out)
                 done(e)
             n = xin.shape[-1] - init_len
             for key, fn in (("ESR", esr_sums), ("DCPreESR", esr_dcpre_sums)):
+                if pre is not None:
+                    s = pre[key]
+                    per[key].append((s[:, 0] / n) / (s[:, 1] / n + ESR_EPS))
+                    continue
                 e = span(key)
                 s = fn(out, tgt, skip=init_len)
                 per[key].append((s[:, 0] / n) / (s[:, 1] / n + ESR_EPS))
@@ -344,7 +358,7 @@ def compute_loss(a, feeder, model, names, delay, is_dd, init_len, rank, world, s
         if rank == 0 and not a.NO_CACHE:
             try:                                   # a cache that cannot be written must never cost the printed results
                 os.makedirs(save_path, exist_ok=True)
-                np.save(cached, dict(results, _key=key, _segments=n_seg))
+                np.save(cached, dict(results, _key=cache_key, _segments=n_seg))
             except OSError as e:
                 say(f"(loss cache not written: {e})")
     say()
