@@ -338,7 +338,12 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     auto dcp_filter = [&](float (&u)[4], float &last, float &state) {
         using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
         using I4 = std::integral_constant<int, 4>; using I8 = std::integral_constant<int, 8>;
-        const float prev = (tid & 15) ? dpp_shr(u[3], I1{}) : last;
+        // the input sample before this thread's four: lane c - 1's last one, for lane 0 of the row the carried one -- as ONE
+        // DPP move whose `old` operand is the carried value (row_shr:1 leaves lane 0 of a row unwritten).  Written as a
+        // select, hipcc sinks the DPP move into the branch of lanes 1..15, where lane 1 then reads an EXEC-disabled lane 0
+        // and gets nothing.
+        const float prev = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, last), __builtin_bit_cast(int, u[3]),
+                                                                                 0x111, 0xf, 0xf, false));
         const float f0 = u[0] - prev;
         const float f1 = __builtin_fmaf(dR1, f0, u[1] - u[0]);
         const float f2 = __builtin_fmaf(dR1, f1, u[2] - u[1]);
