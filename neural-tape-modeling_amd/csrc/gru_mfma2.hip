@@ -326,12 +326,14 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     (void)dcp_e; (void)dcp_t; (void)dcp_ce; (void)dcp_ct; (void)dcp_le; (void)dcp_lt; (void)dR3; (void)dR32; (void)dRc;
     f32x4 esr_used = {0.0f, 0.0f, 0.0f, 0.0f};               // the target values the last esr_accumulate saw
     (void)esr_used;
+    // (bound_ctrl = 1: a lane without a source reads 0, so the move needs no `old` register set up in front of it and
+    //  hipcc can fold it into the consuming v_fmac as a DPP operand)
     auto dpp_shr = [](float x, auto n_c) {                   // lane c of a 16-lane row <- lane c - N (0 where there is none)
         constexpr int N = decltype(n_c)::value;
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x110 + N, 0xf, 0xf, false));
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x110 + N, 0xf, 0xf, true));
     };
     auto dpp_last = [](float x) {                            // every lane of a row <- lane 15 of the row (row_newbcast:15)
-        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x15F, 0xf, 0xf, false));
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x15F, 0xf, 0xf, true));
     };
     // one signal of one tile: u[0..3] = this thread's 4 filter inputs (zero outside [skip, T)), `last` / `state` the row's
     // carried input / output; -> the 4 filter outputs in u, carries moved on
@@ -374,12 +376,18 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         }
         dcp_filter(ue, dcp_le, dcp_ce);
         dcp_filter(ut, dcp_lt, dcp_ct);
+        // the thread's four squares are added in fp32 (relative error 1e-7 of a 4-term sum), the tile's contribution goes
+        // into the fp64 sum: 2 conversions per tile instead of 8 (the streaming kernel converts every sample; the
+        // difference is far inside the 2e-6 by which the two filters' evaluation orders differ)
+        float qe = 0.0f, qt = 0.0f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            if (!WHOLE && !in[c]) continue;                   // (whole tiles ahead of esr_skip add exact zeros)
-            dcp_e += (double)ue[c] * (double)ue[c];
-            dcp_t += (double)ut[c] * (double)ut[c];
+            const bool on = WHOLE || in[c];                   // (whole tiles ahead of esr_skip add exact zeros)
+            qe = __builtin_fmaf(on ? ue[c] : 0.0f, ue[c], qe);
+            qt = __builtin_fmaf(on ? ut[c] : 0.0f, ut[c], qt);
         }
+        dcp_e += (double)qe;
+        dcp_t += (double)qt;
     };
     auto esr_accumulate = [&](int64_t tile, const f32x4 v, auto whole_c) {
         constexpr bool WHOLE = decltype(whole_c)::value;
