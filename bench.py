@@ -892,6 +892,25 @@ def main():
         lm["MultiSTFT_f16x3_vs_exact_mean"] = float(r.mean())
         extra["loss_pass"] = lm
         del y2
+        # the two time-domain losses out of ONE launch (RNN.forward_losses / ntm_gru_forward_losses: ESR + DCPreESR sums in the
+        # recurrent launch's flush) against the timed step's launch + the streaming DCPreESR pass behind it; never part of `value`
+        def timed_loss_leg(fn, n=4):
+            ms_ = []
+            for i in range(n + 1):
+                model.initialize_hidden()
+                model.warm_start()
+                model.hidden = model.hidden.expand(1, B, 64).contiguous()
+                ev0.record(); r_ = fn(); ev1.record(); torch.cuda.synchronize()
+                if i:
+                    ms_.append(ev0.elapsed_time(ev1))
+            return float(np.mean(ms_)), r_
+        ms_l, (_, s_l, d_l) = timed_loss_leg(lambda: model.forward_losses(x, target, INIT_LEN))
+        ms_p, (s_p, d_p) = timed_loss_leg(lambda: (lambda ys: (ys[1], esr_dcpre_sums(ys[0], target, INIT_LEN)))(model.forward_esr(x, target, INIT_LEN)))
+        extra["esr_dcpre_fused"] = {
+            "what": "forward + ESR + DCPreESR sums in one launch (gru_mfma2_kernel<ESR, DCP>) vs the ESR launch + the streaming DCPreESR pass",
+            "one_launch_ms": ms_l, "esr_launch_plus_dcpre_pass_ms": ms_p, "saved_ms": ms_p - ms_l,
+            "esr_sums_identical": bool(torch.equal(s_l, s_p)),
+            "dcpre_sums_max_rel_diff": float(((d_l - d_p).abs() / d_p.abs().clamp_min(1e-300)).max())}
     # achievable HBM rate on this box (state it beside the 8 TB/s vendor peak): device copy of the
     # input batch, read + write bytes over the event time
     cp = torch.empty_like(x)

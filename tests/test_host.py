@@ -222,6 +222,24 @@ def test_step_barrier_wait_count_matches_the_disassembly():
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
+def test_product_kernels_use_no_scratch_and_keep_their_register_budget():
+    """tools/kernel_resources.py --check on the built libntm.so: the code objects' own metadata must show no scratch and no
+    VGPR spill for ANY kernel, and the product instantiations of the recurrent kernel must not exceed the VGPR counts of the
+    binary the committed profiles were measured on (a silent register-allocation change is a performance event); the record
+    the Makefile wrote beside the library describes exactly this library (sha256)."""
+    import hashlib
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"), "--check"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "VGPR pins hold: ok" in r.stdout, r.stderr[-2000:]
+    info = json.load(open(os.path.join(ROOT, "neural-tape-modeling_amd", "build_info.json")))
+    with open(ntm_amd._lib.LIB_PATH, "rb") as f:
+        assert hashlib.sha256(f.read()).hexdigest() == info["library_sha256"]
+    names = [k["kernel"] for k in info["kernels"]]
+    assert any("gru_mfma2_kernel<true, false, 0, 0, 16, false, true, true>" in n for n in names) and any("gru_wide_kernel<true>" in n for n in names)
+    assert info["compiler"]["hip"] and all(k["scratch_bytes"] == 0 and k["vgpr_spills"] == 0 for k in info["kernels"])
+
+
 def test_recorded_bench_line_follows_the_contract():
     """The last default `python bench.py` line recorded on the MI355X (profiles/) carries every field of the driver's
     contract, the roofline of the dominant kernel and the CPU baseline; its numbers are self-consistent."""
