@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Where the evaluation command's decode stage goes (bench.py other_workloads.cli: 488 ms for a 0.9 GB stereo float32 WAV pair):
+one 128 x 441 000-sample stereo float32 file, every step of feeder.read_wav / SegmentFeeder._host timed on its own, beside
+the pieces a device-resident decode would be made of (mmap -> pinned staging chunks -> H2D -> de-interleave on the device).
+usage: python tools/decode_probe.py [n_seg]"""
+import json, os, sys, tempfile, time
+import numpy as np, torch
+from scipy.io import wavfile
+n_seg = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+N = n_seg * 441000 + 777
+tmp = tempfile.mkdtemp(prefix="ntm_dec_", dir="/tmp")
+path = os.path.join(tmp, "input_1_.wav")
+rng = np.random.default_rng(0)
+a = rng.uniform(-0.5, 0.5, (N, 2)).astype(np.float32)
+wavfile.write(path, 44100, a)
+del a
+out = {"bytes": 8 * N}
+def T(name, fn):
+    t0 = time.perf_counter(); r = fn(); out[name + "_ms"] = 1e3 * (time.perf_counter() - t0); return r
+for rep in range(2):            # second round: page cache warm
+    fs, raw = T("wavfile_read", lambda: wavfile.read(path))
+    f32 = T("astype_f32", lambda: raw.astype(np.float32))
+    ct = T("transpose_contiguous", lambda: np.ascontiguousarray(f32.T))
+    pin = T("pin_memory", lambda: torch.from_numpy(ct).pin_memory())
+    dev = T("h2d_whole", lambda: (pin.cuda(non_blocking=True), torch.cuda.synchronize())[0])
+    del raw, f32, ct, pin, dev
+# the alternative: mmap, one pinned staging buffer reused, interleaved H2D in chunks, de-interleave on the device
+fs, mm = T("wavfile_mmap", lambda: wavfile.read(path, mmap=True))
+CH = 8 << 20                                           # frames per chunk (64 MB of stereo float32)
+stage = [T("pinned_staging_alloc", lambda: torch.empty(CH, 2, dtype=torch.float32).pin_memory()) for _ in range(2)]
+res = torch.empty(2, N, device="cuda")
+inter = [torch.empty(CH, 2, device="cuda") for _ in range(2)]
+evs = [torch.cuda.Event() for _ in range(2)]
+torch.cuda.synchronize()
+def resident():
+    k = 0
+    for f0 in range(0, N, CH):
+        n = min(CH, N - f0)
+        b = k & 1
+        evs[b].synchronize()                            # the staging buffer's previous copy has left
+        stage[b].numpy()[:n] = mm[f0:f0 + n]            # the one host pass: page cache -> pinned
+        inter[b][:n].copy_(stage[b][:n], non_blocking=True)
+        res[:, f0:f0 + n].copy_(inter[b][:n].t())       # de-interleave on the device
+        evs[b].record()
+        k += 1
+    torch.cuda.synchronize()
+T("resident_decode_first", resident)
+T("resident_decode", resident)
+fs, raw = wavfile.read(path)
+out["resident_equals_host_decode"] = bool(torch.equal(res.cpu(), torch.from_numpy(np.ascontiguousarray(raw.T))))
+print(json.dumps(out))
+import shutil; shutil.rmtree(tmp, ignore_errors=True)

@@ -15,4 +15,5 @@ timeout 600 $PY bench.py --workload diffdel --steps 10 --warmup 2 > "$OUT/${TAG}
 timeout 600 $PY bench.py --workload tcn --steps 10 --warmup 2 > "$OUT/${TAG}_bench_tcn.json" 2> "$OUT/${TAG}_bench_tcn.err"; echo "bench tcn exit $?"
 bash tools/profile_all.sh $TAG gru diffdel tcn tape losses
 rm -rf "$OUT"/${TAG}_prof_*
+timeout 300 $PY tools/decode_probe.py > "$OUT/${TAG}_decode_probe.json" 2>&1; tail -n 1 "$OUT/${TAG}_decode_probe.json"
 cat "$OUT/.graft_exec_refused" 2>/dev/null | tail -3
