@@ -64,7 +64,7 @@ def synth_input(B, T, device, seed):
     return x.unsqueeze(1)
 
 
-def cpu_baseline(w_name):
+def cpu_baseline(w_name, small=False):
     """Reference CPU path timed on this host: stock torch.nn.GRU + Linear on CPU -- the modules the
     reference builds at code/model.py:44-45 -- with the CHOWTAPE weights under inference_mode, on the two shapes the
     survey names: 16 x 8192 (BASELINE configs[0], the reference's best CPU shape; `value`) and 64 x 8192; a bounded
@@ -84,7 +84,7 @@ def cpu_baseline(w_name):
     f = oracle.torch_gru_port(w)
     f(rng.uniform(-0.5, 0.5, (16, 512)).astype(np.float32), np.repeat(oracle.warm_state(w), 16, 0))   # thread-pool warm-up
     shapes = {}
-    for B, T, reps in ((16, 8192, 3), (64, 8192, 1)):
+    for B, T, reps in (((16, 8192, 1),) if small else ((16, 8192, 3), (64, 8192, 1))):
         h0 = np.repeat(oracle.warm_state(w), B, 0)
         x = rng.uniform(-0.5, 0.5, (B, T)).astype(np.float32)
         best = None
@@ -95,8 +95,8 @@ def cpu_baseline(w_name):
             best = dt if best is None else min(best, dt)
         shapes[f"{B}x{T}"] = {"value": x.size / best, "seconds": best, "repetitions": reps}
     res = {"value": shapes["16x8192"]["value"], "unit": "samples/s", "cores": cores, "kind": "port",
-           "sample": f"16 x 8192 samples (BASELINE configs[0] shape) of the same workload, best of 3, torch.nn.GRU+Linear "
-                     f"on CPU under inference_mode, {cores} threads; 64 x 8192 beside it",
+           "sample": f"16 x 8192 samples (BASELINE configs[0] shape) of the same workload, best of {1 if small else 3}, torch.nn.GRU+Linear "
+                     f"on CPU under inference_mode, {cores} threads" + ("" if small else "; 64 x 8192 beside it"),
            "shapes": shapes}
     xo = rng.uniform(-0.5, 0.5, (2 * cores, 8192)).astype(np.float32)
     t0 = time.perf_counter()
@@ -661,6 +661,8 @@ def main():
     ap.add_argument("--total-batch", type=int, default=32768, help="segments of the whole job under --scaling strong")
     ap.add_argument("--variant", default="auto", choices=["auto", "mfma2", "mfma4", "mfma", "valu", "f16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="full", choices=["full", "small"],
+                    help="cpu_baseline: full = 16 x 8192 best of 3 + 64 x 8192 (about 10 s); small = 16 x 8192 once (tests)")
     ap.add_argument("--no-extra", action="store_true", help="skip the opt-in f16x3 kernel leg")
     ap.add_argument("--other", default="auto", choices=["auto", "on", "off"],
                     help="attach `other_workloads` (configs[2], [3] and the per-GPU shapes of configs[4]) to the line: "
@@ -1043,7 +1045,7 @@ def main():
         out["other_kernels"] = extra
     if not a.no_cpu_baseline:
         # N > 1: rank 0 alone, after the process group is gone (the other ranks have left; nothing of this is timed)
-        out["cpu_baseline"] = cpu_baseline(weights.W_GRU)
+        out["cpu_baseline"] = cpu_baseline(weights.W_GRU, small=a.cpu_sample == "small")
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         # CPU leg, outside the timed region: scattered streams of the LAST timed step's output (rank 0's rows) against the C
         # oracle over the whole sequence (the oracle is the checker here, never the thing measured)

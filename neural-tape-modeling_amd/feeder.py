@@ -35,20 +35,32 @@ from . import _lib
 from ._lib import ptr
 
 
-def read_wav(path):
-    """-> (float32 [C, N], fs); integer PCM is scaled by 2^(bits-1) like torchaudio.load(normalize=True)."""
-    fs, a = wavfile.read(path)
+def read_wav(path, pin=False):
+    """-> (float32 [C, N], fs); integer PCM is scaled by 2^(bits-1) like torchaudio.load(normalize=True).
+    The file is memory-mapped and de-interleaved in ONE parallel pass (torch's strided copy on all host cores: a 450 MB
+    stereo file takes ~20 ms where wavfile.read + astype + a numpy transpose took 115 -- the decode is what bounds the
+    evaluation command, bench.py other_workloads.cli); `pin=True` returns a torch tensor in pinned host memory instead of
+    a numpy array (what SegmentFeeder keeps when a HIP device is present)."""
+    import warnings
+    try:
+        fs, a = wavfile.read(path, mmap=True)
+    except (ValueError, OSError):                # formats scipy cannot map (24-bit PCM, a data chunk it has to repack)
+        fs, a = wavfile.read(path)
     if a.ndim == 1:
         a = a[:, None]
-    if a.dtype == np.int16:
-        a = a.astype(np.float32) / 32768.0
-    elif a.dtype == np.int32:
-        a = a.astype(np.float32) / 2147483648.0
-    elif a.dtype == np.uint8:
-        a = (a.astype(np.float32) - 128.0) / 128.0
-    else:
-        a = a.astype(np.float32)
-    return np.ascontiguousarray(a.T), int(fs)
+    # (offset, scale) of integer PCM; every step below is exact in fp32 or rounds exactly as `astype(np.float32)` did
+    pcm = {np.dtype(np.int16): (0.0, 1.0 / 32768.0), np.dtype(np.int32): (0.0, 1.0 / 2147483648.0),
+           np.dtype(np.uint8): (-128.0, 1.0 / 128.0)}.get(a.dtype)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # "the given NumPy array is not writable": it is only read
+        t = torch.from_numpy(a)
+    out = torch.empty(a.shape[1], a.shape[0], dtype=torch.float32, pin_memory=bool(pin and torch.cuda.is_available()))
+    out.copy_(t.t())                             # de-interleave + convert to fp32, one pass
+    if pcm is not None:
+        if pcm[0]:
+            out.add_(pcm[0])
+        out.mul_(pcm[1])
+    return (out if pin else out.numpy()), int(fs)
 
 
 def _file_id(path):
@@ -209,7 +221,8 @@ class SegmentFeeder:
         for idx, (ifile, tfile) in enumerate(zip(self.input_files, self.target_files)):
             if not input_only and _file_id(ifile) != _file_id(tfile):
                 raise RuntimeError(f"Found non-matching file ids: {_file_id(ifile)} != {_file_id(tfile)}! Check dataset.")
-            x, fs = read_wav(ifile)
+            pin = torch.cuda.is_available()
+            x, fs = read_wav(ifile, pin=pin)
             self.fs = self.fs or fs
             if fs != self.fs:
                 raise RuntimeError("Framerate not constant across dataset.")
@@ -220,7 +233,7 @@ class SegmentFeeder:
                 raise ValueError(f"Sequence length `{self.length}` is longer than file length `{num_frames}`.")
             t = None
             if not input_only:
-                t, _ = read_wav(tfile)
+                t, _ = read_wav(tfile, pin=pin)
                 if x.shape[-1] != t.shape[-1]:
                     raise RuntimeError("Found potentially corrupt file!")
             # the side-car sits next to its input file under the input's own name (code/utilities/utilities.py:273-275):
@@ -230,7 +243,7 @@ class SegmentFeeder:
             if d is None and analyze and t is not None and x.shape[0] > 1 and t.shape[0] > 1:
                 # stereo pair without a side-car: analyse the pilot channels as DelayAnalyzer does on first use
                 # (code/utilities/utilities.py:306-335) and cache the result next to the audio in its format
-                xi, yi, T_delay, xm, ym = analyze_delay(x[1].astype(np.float64), t[1].astype(np.float64), fs)
+                xi, yi, T_delay, xm, ym = analyze_delay(np.asarray(x[1], np.float64), np.asarray(t[1], np.float64), fs)
                 if write_sidecars:
                     try:
                         write_sidecar(sidecar, xi, yi, T_delay, xm, ym)
@@ -239,13 +252,14 @@ class SegmentFeeder:
                 d = {"delay_trajectory": np.asarray(T_delay, np.float64), "input_peaks": xi.astype(np.int64),
                      "output_peaks": yi.astype(np.int64)}
             if d is not None:                                                          # utilities.py:296-300
-                self.mean_delay += float(np.mean(d["delay_trajectory"]))
-                self.max_delay = max(self.max_delay, float(np.max(d["delay_trajectory"])))
-                self.min_delay = min(self.min_delay, float(np.min(d["delay_trajectory"])))
+                tr = torch.from_numpy(np.ascontiguousarray(d["delay_trajectory"]))
+                self.mean_delay += float(np.mean(d["delay_trajectory"]))              # (numpy's pairwise sum, as the reference)
+                self.max_delay = max(self.max_delay, float(tr.max()))                 # max / min / the fp32 copy: exact in any
+                self.min_delay = min(self.min_delay, float(tr.min()))                 # order, so on all host cores (torch)
             # whole files live in PINNED host memory when a HIP device is present: a batch then goes to the device
             # as a few large DMA copies straight from here (no per-batch staging copy on the host)
             if d is not None:
-                d["traj_f32"] = self._host(np.ascontiguousarray(d["delay_trajectory"], np.float32)[None, :])
+                d["traj_f32"] = self._host(tr.to(torch.float32)[None, :].contiguous().numpy())
             self._audio.append((self._host(x), None if t is None else self._host(t), d))
             start = int(self.sync * self.fs)
             for n_chunk in range((num_frames - start) // self.length):
@@ -268,6 +282,8 @@ class SegmentFeeder:
 
     @staticmethod
     def _host(a):
+        if isinstance(a, torch.Tensor):              # read_wav(pin=True) already decoded into pinned memory
+            return a
         t = torch.from_numpy(a)
         if torch.cuda.is_available():
             try:

@@ -242,3 +242,31 @@ def test_fraction_and_shuffle_select_examples_like_create_fractional_patches(tmp
     got = np.concatenate([x.numpy()[:, 0] for x, _, _, _ in a.batches(4, device="cpu")])
     want = np.stack([data[e["idx"]][0][e["offset"]:e["offset"] + 2000] for e in a.examples])
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("dtype", [np.int16, np.int32, np.uint8, np.float32, np.float64])
+@pytest.mark.parametrize("channels", [1, 2])
+def test_read_wav_formats_are_decoded_as_before(tmp_path, dtype, channels):
+    """read_wav maps the file and de-interleaves it in one torch pass (round 5: the decode bounds the evaluation command);
+    the values must be those of the plain numpy definition -- integer PCM scaled by 2^(bits-1) like
+    torchaudio.load(normalize=True), uint8 offset by 128, float64 rounded to float32 -- for mono and stereo files."""
+    from scipy.io import wavfile
+    from ntm_amd.feeder import read_wav
+    rng = np.random.default_rng(7)
+    N = 5003
+    if dtype == np.uint8:
+        a = rng.integers(0, 256, (N, channels)).astype(dtype)
+        want = (a.astype(np.float32) - 128.0) / 128.0
+    elif dtype in (np.int16, np.int32):
+        info = np.iinfo(dtype)
+        a = rng.integers(info.min, info.max, (N, channels), endpoint=True).astype(dtype)
+        a[0], a[1] = info.min, info.max
+        want = a.astype(np.float32) / np.float32(-float(info.min))
+    else:
+        a = rng.uniform(-1, 1, (N, channels)).astype(dtype)
+        want = a.astype(np.float32)
+    path = str(tmp_path / "f.wav")
+    wavfile.write(path, 22050, a[:, 0] if channels == 1 else a)
+    got, fs = read_wav(path)
+    assert fs == 22050 and got.dtype == np.float32 and got.shape == (channels, N) and got.flags["C_CONTIGUOUS"]
+    assert np.array_equal(got, want.T)

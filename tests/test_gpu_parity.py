@@ -194,8 +194,10 @@ def test_variants_agree_and_raw_abi_strides(ntm):
 
 def test_abi_errors(ntm):
     L = ntm._lib.lib()
+    assert L.ntm_gru_forward(None, None, None, None, None, None, 1025, None, None, 1, 1, 1, 1, None, None) == -1
+    assert b"[1, 1024]" in L.ntm_last_error()
     assert L.ntm_gru_forward(None, None, None, None, None, None, 24, None, None, 1, 1, 1, 1, None, None) == -1
-    assert b"8, 16, 32 and 64" in L.ntm_last_error()
+    assert b"null pointer" in L.ntm_last_error()                  # round 5: any hidden size in range is taken
     assert L.ntm_gru_forward(None, None, None, None, None, None, 64, None, None, 0, 10, 10, 10, None, None) == 0
     assert L.ntm_gru_forward(None, None, None, None, None, None, 64, None, None, 2, 10, 10, 10, None, None) == -1
     m = make_rnn(ntm)
@@ -872,7 +874,7 @@ def test_c_abi_from_a_plain_cpp_process(ntm, tmp_path):
     r = subprocess.run([exe, wfile, str(tmp_path / "x.f32"), str(B), str(T), str(tmp_path / "y.f32"), str(tmp_path / "h.f32")],
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
-    assert "8, 16, 32 and 64 are compiled" in r.stdout            # the refusal message of the error-path call
+    assert "hidden size must lie in [1, 1024]" in r.stdout        # the refusal message of the error-path call
     y = np.fromfile(str(tmp_path / "y.f32"), np.float32).reshape(B, T)
     h = np.fromfile(str(tmp_path / "h.f32"), np.float32).reshape(B, 64)
     yo, ho = oracle.gru_forward(oracle_weights(W_G), x)

@@ -259,9 +259,10 @@ def _diffdel_entry_point_raw_ctypes(ntm):
     assert _dd_call(L, w, x, d, y, y, h, buf, D2, flag) == -1 and b"distinct" in L.ntm_last_error()
     assert L.ntm_diffdel_gru_forward(p(w["GRU.weight_ih_l0"]), p(w["GRU.weight_hh_l0"]), p(w["GRU.bias_ih_l0"]), p(w["GRU.bias_hh_l0"]),
                                      p(w["output.weight"]), 64, p(x), p(d), p(y), None, B, T, p(h), p(buf), D2, 0, p(flag), None) == -1
-    # hidden size the library does not compile: refused through this entry as well
+    # a hidden size outside [1, NTM_MAX_HIDDEN]: refused through this entry as well
     assert L.ntm_diffdel_gru_forward(p(w["GRU.weight_ih_l0"]), p(w["GRU.weight_hh_l0"]), p(w["GRU.bias_ih_l0"]), p(w["GRU.bias_hh_l0"]),
-                                     p(w["output.weight"]), 24, p(x), p(d), p(y), p(pre), B, T, p(h), p(buf), D2, 0, p(flag), None) == -1
+                                     p(w["output.weight"]), 2000, p(x), p(d), p(y), p(pre), B, T, p(h), p(buf), D2, 0, p(flag), None) == -1
+    assert b"[1, 1024]" in L.ntm_last_error()
 
     # a delay beyond D in ONE stream: the flag goes up, the delay state of EVERY stream stays as it was (the reference
     # asserts before it touches its buffer, code/model.py:284), the GRU state moves on (self.hidden is assigned at :412)
@@ -366,7 +367,8 @@ def test_bench_line_carries_the_other_workloads():
     as `other_workloads` (here at small shapes, `--other on`): each with kernel, kernel_ms, roofline.frac, determinism
     and scattered streams against the oracle; the headline fields are those of a run without them."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "1040",
-                        "--samples", "4096", "--no-extra", "--other", "on", "--other-steps", "2", "--other-gru-batches", "2048,4112", "--other-tcn-batches", "2048"],
+                        "--samples", "4096", "--no-extra", "--other", "on", "--other-steps", "2", "--other-gru-batches", "2048,4112", "--other-tcn-batches", "2048",
+                        "--cli-segments", "0"],              # (other_workloads.cli: tests/test_gpu_round5.py)
                        env=_clean_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])

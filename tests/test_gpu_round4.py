@@ -352,6 +352,7 @@ def test_full_size_eight_rank_dry_run_on_one_gpu():
     the one-rank job's data (stream 0 = golden g6 against the REFERENCE's output, same number in both).
     Reference counterpart: none (scripts/sbatch-train-exp1a.sh:7 runs replicas only)."""
     common = ["--steps", "2", "--warmup", "1", "--no-extra", "--other", "off"]
+    common = common + ["--cpu-sample", "small"]      # (the CPU leg's 64 x 8192 shape and second repetitions: the default line has them)
     weak = _bench(["--gpus", "8"] + common, NTM_DIST_BACKEND="gloo")
     assert weak["n_gpus"] == 8 and weak["ranks"] == 8 and weak["backend"] == "gloo" and weak["rccl_ranks"] == 0
     assert [d["rank"] for d in weak["rank_devices"]] == list(range(8)) and all(d["device"] == 0 for d in weak["rank_devices"])

@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 PY=$(command -v python3)
 TAG=${1:-r05_f}
 rm -f "$OUT/r05_checkpoint_parity.jsonl"
-( time timeout 3300 $PY -m pytest tests -q -m gpu ) > "$OUT/${TAG}_tests.log" 2>&1; echo "tests exit $?"; tail -n 8 "$OUT/${TAG}_tests.log" | cut -c1-300
+( time timeout 3300 $PY -m pytest tests -q -m gpu --durations=15 ) > "$OUT/${TAG}_tests.log" 2>&1; echo "tests exit $?"; tail -n 28 "$OUT/${TAG}_tests.log" | cut -c1-300
 timeout 600 $PY __graft_entry__.py smoke > "$OUT/${TAG}_smoke.log" 2>&1; echo "smoke exit $?"; tail -n 3 "$OUT/${TAG}_smoke.log"
 ( time timeout 900 $PY bench.py ) > "$OUT/${TAG}_bench_default.json" 2> "$OUT/${TAG}_bench_default.err"; echo "bench exit $?"; tail -n 4 "$OUT/${TAG}_bench_default.err"
 timeout 600 $PY bench.py --workload diffdel --steps 10 --warmup 2 > "$OUT/${TAG}_bench_diffdel.json" 2> "$OUT/${TAG}_bench_diffdel.err"; echo "bench diffdel exit $?"
