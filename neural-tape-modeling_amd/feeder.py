@@ -19,6 +19,9 @@ below = code/utilities/utilities.py:343-406, :466-610, pinned by golden g12) and
 `fraction` / `shuffle` select the examples as `create_fractional_patches` does (code/dataset.py:295-341, one device
 configuration): the first `int(len * fraction)` segments, or with `shuffle=True` that many drawn WITH replacement by
 `np.random.randint` (the reference's global, unseeded generator; `seed` makes the draw repeatable here).
+Where the set lives (round 5): on a HIP device whose memory it fits (always, in practice: 288 GB) the decode IS the
+host-to-device copy (read_wav_device) and the set stays resident -- batches are device-to-device gathers; otherwise whole
+files sit in pinned host memory and batches are large DMA copies (`resident=False` forces this layout).
 What is NOT kept (out of scope): half/double storage, un-preloaded operation.
 The dataset itself (Zenodo 8026272) is not available here, so this module is checked against synthetic
 files only (tests/test_feeder.py).
@@ -35,32 +38,73 @@ from . import _lib
 from ._lib import ptr
 
 
-def read_wav(path, pin=False):
-    """-> (float32 [C, N], fs); integer PCM is scaled by 2^(bits-1) like torchaudio.load(normalize=True).
-    The file is memory-mapped and de-interleaved in ONE parallel pass (torch's strided copy on all host cores: a 450 MB
-    stereo file takes ~20 ms where wavfile.read + astype + a numpy transpose took 115 -- the decode is what bounds the
-    evaluation command, bench.py other_workloads.cli); `pin=True` returns a torch tensor in pinned host memory instead of
-    a numpy array (what SegmentFeeder keeps when a HIP device is present)."""
-    import warnings
+_PCM = {np.dtype(np.int16): (0.0, 32768.0), np.dtype(np.int32): (0.0, 2147483648.0), np.dtype(np.uint8): (128.0, 128.0)}
+
+
+def read_wav(path):
+    """-> (float32 [C, N] numpy, fs); integer PCM is scaled by 2^(bits-1) like torchaudio.load(normalize=True).  The host-side
+    decode (no HIP device, or a dataset that does not fit the device: SegmentFeeder(resident=False))."""
+    fs, a = wavfile.read(path)
+    if a.ndim == 1:
+        a = a[:, None]
+    if a.dtype in _PCM:
+        off, div = _PCM[a.dtype]
+        a = (a.astype(np.float32) - np.float32(off)) / np.float32(div) if off else a.astype(np.float32) / np.float32(div)
+    else:
+        a = a.astype(np.float32, copy=False)
+    return np.ascontiguousarray(a.T), int(fs)
+
+
+_STAGE_BYTES = 64 << 20
+_stage = {}          # device index -> two pinned staging buffers + the events that guard their reuse
+
+
+def read_wav_device(path, device="cuda"):
+    """-> (float32 [C, N] tensor ON THE DEVICE, fs), the same values as read_wav.  The decode IS the host-to-device copy:
+    the file is memory-mapped, its interleaved frames go through two pinned 64 MB staging buffers (the one host pass: page
+    cache -> pinned) and over PCIe as they are, and the de-interleave, the conversion to fp32 and the PCM scaling run on the
+    device -- a 450 MB stereo float32 file takes 14 ms (tools/decode_probe.py) where wavfile.read + the numpy transpose +
+    pinning took 115 on the host.  With 288 GB of HBM a whole evaluation set lives on the device; SegmentFeeder falls back
+    to the pinned-host layout when it does not fit."""
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     try:
         fs, a = wavfile.read(path, mmap=True)
-    except (ValueError, OSError):                # formats scipy cannot map (24-bit PCM, a data chunk it has to repack)
+    except (ValueError, OSError):                    # formats scipy cannot map (24-bit PCM: it repacks the samples)
         fs, a = wavfile.read(path)
     if a.ndim == 1:
         a = a[:, None]
-    # (offset, scale) of integer PCM; every step below is exact in fp32 or rounds exactly as `astype(np.float32)` did
-    pcm = {np.dtype(np.int16): (0.0, 1.0 / 32768.0), np.dtype(np.int32): (0.0, 1.0 / 2147483648.0),
-           np.dtype(np.uint8): (-128.0, 1.0 / 128.0)}.get(a.dtype)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")          # "the given NumPy array is not writable": it is only read
-        t = torch.from_numpy(a)
-    out = torch.empty(a.shape[1], a.shape[0], dtype=torch.float32, pin_memory=bool(pin and torch.cuda.is_available()))
-    out.copy_(t.t())                             # de-interleave + convert to fp32, one pass
-    if pcm is not None:
-        if pcm[0]:
-            out.add_(pcm[0])
-        out.mul_(pcm[1])
-    return (out if pin else out.numpy()), int(fs)
+    N, C = a.shape
+    tdt = {np.dtype(np.int16): torch.int16, np.dtype(np.int32): torch.int32, np.dtype(np.uint8): torch.uint8,
+           np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}.get(a.dtype)
+    if tdt is None or not a.dtype.isnative:
+        x, fs = read_wav(path)
+        return torch.from_numpy(x).to(dev), fs
+    st = _stage.get(dev.index)
+    if st is None:
+        st = _stage[dev.index] = {"host": [torch.empty(_STAGE_BYTES, dtype=torch.uint8).pin_memory() for _ in range(2)],
+                                  "dev": [torch.empty(_STAGE_BYTES, dtype=torch.uint8, device=dev) for _ in range(2)],
+                                  "ev": [torch.cuda.Event(), torch.cuda.Event()]}
+    frame = a.dtype.itemsize * C
+    per = max(1, _STAGE_BYTES // frame)
+    out = torch.empty(C, N, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        for k, f0 in enumerate(range(0, N, per)):
+            n, b = min(per, N - f0), k & 1
+            st["ev"][b].synchronize()                # this staging pair's previous chunk has left it
+            hv = st["host"][b][:n * frame]
+            hv.numpy().view(a.dtype).reshape(n, C)[...] = a[f0:f0 + n]
+            dv = st["dev"][b][:n * frame]
+            dv.copy_(hv, non_blocking=True)
+            out[:, f0:f0 + n].copy_(dv.view(tdt).view(n, C).t())      # de-interleave + convert on the device
+            st["ev"][b].record()
+        if a.dtype in _PCM:                          # the same fp32 operations as read_wav: exact (powers of two)
+            off, div = _PCM[a.dtype]
+            if off:
+                out.sub_(off)
+            out.div_(div)
+    return out, int(fs)
 
 
 def _file_id(path):
@@ -199,7 +243,7 @@ def demodulate(output, x_idx_pulse, y_idx_pulse):
 
 class SegmentFeeder:
     def __init__(self, data_dir, subset="train", length=44100, input_only=False, sync=0.0, demodulate=False,
-                 analyze=True, write_sidecars=True, fraction=1.0, shuffle=False, seed=None):
+                 analyze=True, write_sidecars=True, fraction=1.0, shuffle=False, seed=None, resident=None):
         assert os.path.exists(data_dir), "Can't find chosen data_dir"
         assert not (input_only and demodulate), "Can't demodulate without inputs"       # code/dataset.py:68
         self.data_dir, self.subset, self.length, self.input_only, self.sync = data_dir, subset, length, input_only, sync
@@ -218,11 +262,20 @@ class SegmentFeeder:
         self.fs = None
         self.examples = []
         self._audio = []
+        # `resident`: the decoded set lives ON THE DEVICE (read_wav_device: the decode is the H2D copy; batches are then
+        # device-to-device gathers and predict_streamed one launch).  None = yes when a HIP device is present and the files
+        # (fp32 audio + fp32 trajectories, ~1.5 x their size on disk at worst) fit half of its free memory; False = the
+        # pinned-host layout with H2D copies per batch (what a set larger than the device needs).
+        if resident is None:
+            resident = False
+            if torch.cuda.is_available():
+                need = 2 * sum(os.path.getsize(f) for f in self.input_files + [t for t in self.target_files if t])
+                resident = need < 0.5 * torch.cuda.mem_get_info()[0]
+        self.resident = bool(resident)
         for idx, (ifile, tfile) in enumerate(zip(self.input_files, self.target_files)):
             if not input_only and _file_id(ifile) != _file_id(tfile):
                 raise RuntimeError(f"Found non-matching file ids: {_file_id(ifile)} != {_file_id(tfile)}! Check dataset.")
-            pin = torch.cuda.is_available()
-            x, fs = read_wav(ifile, pin=pin)
+            x, fs = read_wav_device(ifile) if self.resident else read_wav(ifile)
             self.fs = self.fs or fs
             if fs != self.fs:
                 raise RuntimeError("Framerate not constant across dataset.")
@@ -233,7 +286,7 @@ class SegmentFeeder:
                 raise ValueError(f"Sequence length `{self.length}` is longer than file length `{num_frames}`.")
             t = None
             if not input_only:
-                t, _ = read_wav(tfile, pin=pin)
+                t, _ = read_wav_device(tfile) if self.resident else read_wav(tfile)
                 if x.shape[-1] != t.shape[-1]:
                     raise RuntimeError("Found potentially corrupt file!")
             # the side-car sits next to its input file under the input's own name (code/utilities/utilities.py:273-275):
@@ -243,7 +296,8 @@ class SegmentFeeder:
             if d is None and analyze and t is not None and x.shape[0] > 1 and t.shape[0] > 1:
                 # stereo pair without a side-car: analyse the pilot channels as DelayAnalyzer does on first use
                 # (code/utilities/utilities.py:306-335) and cache the result next to the audio in its format
-                xi, yi, T_delay, xm, ym = analyze_delay(np.asarray(x[1], np.float64), np.asarray(t[1], np.float64), fs)
+                pilot = lambda a: (a[1].cpu().numpy() if isinstance(a, torch.Tensor) else a[1]).astype(np.float64)   # noqa: E731
+                xi, yi, T_delay, xm, ym = analyze_delay(pilot(x), pilot(t), fs)
                 if write_sidecars:
                     try:
                         write_sidecar(sidecar, xi, yi, T_delay, xm, ym)
@@ -256,10 +310,12 @@ class SegmentFeeder:
                 self.mean_delay += float(np.mean(d["delay_trajectory"]))              # (numpy's pairwise sum, as the reference)
                 self.max_delay = max(self.max_delay, float(tr.max()))                 # max / min / the fp32 copy: exact in any
                 self.min_delay = min(self.min_delay, float(tr.min()))                 # order, so on all host cores (torch)
-            # whole files live in PINNED host memory when a HIP device is present: a batch then goes to the device
-            # as a few large DMA copies straight from here (no per-batch staging copy on the host)
+            # resident: everything is on the device already.  Otherwise whole files live in PINNED host memory when a HIP
+            # device is present: a batch then goes to the device as a few large DMA copies straight from here (no per-batch
+            # staging copy on the host)
             if d is not None:
-                d["traj_f32"] = self._host(tr.to(torch.float32)[None, :].contiguous().numpy())
+                t32 = tr.to(torch.float32)[None, :].contiguous()
+                d["traj_f32"] = t32.pin_memory().to(x.device, non_blocking=True) if self.resident else self._host(t32.numpy())
             self._audio.append((self._host(x), None if t is None else self._host(t), d))
             start = int(self.sync * self.fs)
             for n_chunk in range((num_frames - start) // self.length):
@@ -279,10 +335,12 @@ class SegmentFeeder:
             pick = np.arange(n_use)
         self.examples = [self.examples[i] for i in pick]
         self.minutes = self.length * len(self.examples) / self.fs / 60
+        if self.resident:
+            torch.cuda.synchronize()         # the decode's copies and kernels are done: any stream may read the set now
 
     @staticmethod
     def _host(a):
-        if isinstance(a, torch.Tensor):              # read_wav(pin=True) already decoded into pinned memory
+        if isinstance(a, torch.Tensor):              # resident: decoded on the device
             return a
         t = torch.from_numpy(a)
         if torch.cuda.is_available():
@@ -301,11 +359,11 @@ class SegmentFeeder:
         o, e = ex["offset"], ex["offset"] + self.length
         name = lambda p: "{0}_[{2}:{3}]{1}".format(*os.path.splitext(os.path.basename(p)), o, e)   # noqa: E731
         meta = {"input_name": name(self.input_files[ex["idx"]])}
-        inp = x[:, o:e]
+        inp = x[:, o:e].cpu()            # items are HOST tensors like the reference's (a no-op for the pinned-host layout)
         if self.input_only:
             return inp, meta
         meta["target_name"] = name(self.target_files[ex["idx"]])
-        tgt = t[:, o:e]
+        tgt = t[:, o:e].cpu()
         if d is not None:
             T_delay = torch.from_numpy(d["delay_trajectory"][o:e].astype(np.float32))
             pin, pout = segment_peaks(d["input_peaks"], d["output_peaks"], o, e, self.length)
@@ -349,6 +407,8 @@ class SegmentFeeder:
         lib = _lib.lib()
         from .model import DiffDelRNN
         is_dd = isinstance(model, DiffDelRNN)
+        if self.resident:
+            return self._predict_resident(model, b0, b1, is_dd, device, out_host)
         x = torch.empty(B, 1, L, device=device, dtype=torch.float32)
         t = None if self.input_only else torch.empty(B, 1, L, device=device, dtype=torch.float32)
         y = torch.empty(B, 1, L, device=device, dtype=torch.float32)
@@ -420,6 +480,33 @@ class SegmentFeeder:
         for a in (x, t, dtr):
             if a is not None:
                 a.record_stream(side)
+        return y, x, t
+
+    @torch.no_grad()
+    def _predict_resident(self, model, b0, b1, is_dd, device, out_host):
+        """predict_streamed for a device-resident set: the segments are gathered device-to-device (one copy per run of
+        consecutive segments) and the whole sequence is ONE launch -- there is no PCIe transfer left to hide."""
+        B, L = b1 - b0, self.length
+
+        def gather(which):
+            dst = torch.empty(B, 1, L, device=device, dtype=torch.float32)
+            for k0, n, idx, off in self.runs(b0, b1):
+                src = self._audio[idx][which]
+                if which == 2:
+                    src = src["traj_f32"]
+                dst[k0:k0 + n, 0].copy_(src[0, off:off + n * L].view(n, L))
+            return dst
+        x = gather(0)
+        t = None if self.input_only else gather(1)
+        if is_dd:
+            assert all(self._audio[self.examples[i]["idx"]][2] is not None for i in range(b0, b1)), \
+                "DiffDelGRU needs delay trajectories (stereo dataset or side-cars)"
+            y = model.predict(x, gather(2) * float(self.fs))[0]
+        else:
+            y = model.predict(x)
+        if out_host is not None:
+            assert tuple(out_host.shape) == (B, 1, L) and out_host.dtype == torch.float32 and out_host.is_contiguous()
+            out_host.copy_(y, non_blocking=True)                # the caller synchronises before reading it
         return y, x, t
 
     def batches(self, batch_size, device="cuda", rank=0, world=1, prefetch=True, timing=None):

@@ -705,7 +705,8 @@ def test_abi_alignment_checks(ntm):
     assert rc != 0 and b"aligned" in LAB.ntm_lab_last_error()
 
 
-def test_streamed_predict_from_pinned_host(ntm, tmp_path):
+@pytest.mark.parametrize("resident", [False, True])
+def test_streamed_predict_from_pinned_host(ntm, tmp_path, resident):
     """N2: time-pipelined predict straight from the feeder's pinned files (pitched DMA chunks on a side stream, the
     GRU launch per chunk on the compute stream, state carried) == one resident launch, bit for bit; input and
     target arrive intact; runs of consecutive segments are found across file boundaries."""
@@ -719,7 +720,8 @@ def test_streamed_predict_from_pinned_host(ntm, tmp_path):
         x = (rng.uniform(-0.5, 0.5, nseg * L + 17 * i) * 32767).astype(np.int16)
         wavfile.write(str(d / f"input_{i}_.wav"), 44100, x)
         wavfile.write(str(d / f"target_{i}_.wav"), 44100, (0.5 * x).astype(np.int16))
-    f = SegmentFeeder(str(tmp_path / "Set"), subset="test", length=L)
+    f = SegmentFeeder(str(tmp_path / "Set"), subset="test", length=L, resident=resident)     # round 5: resident = the set on the device
+    assert f.resident is resident
     assert len(f) == 8 and [r[:2] for r in f.runs(1, 8)] == [(0, 2), (2, 1), (3, 4)]
     m = make_rnn(ntm, W_G, "mfma2")
     xin, tgt, _, _ = next(f.batches(8, "cuda"))
@@ -923,7 +925,8 @@ def test_val_loss_supervised_bundle(ntm):
         assert c == co and np.allclose(s.cpu().numpy(), so, rtol=1e-4), (skip, n_fft, s.cpu().numpy() / so - 1)
 
 
-def test_streamed_predict_diffdel(ntm, tmp_path):
+@pytest.mark.parametrize("resident", [False, True])
+def test_streamed_predict_diffdel(ntm, tmp_path, resident):
     """Time-pipelined predict for DiffDelGRU (audio + delay trajectory sent chunk by chunk, GRU and delay-line state
     carried) == the resident one-shot predict, bit for bit."""
     from scipy.io import wavfile
@@ -937,7 +940,7 @@ def test_streamed_predict_diffdel(ntm, tmp_path):
     wavfile.write(str(d / "input_0_.wav"), fs, np.stack([audio, g["in0"]], 1))
     wavfile.write(str(d / "target_0_.wav"), fs, np.stack([0.5 * audio, g["out0"]], 1))
     L = 7000
-    f = SegmentFeeder(str(tmp_path / "Wow"), subset="test", length=L)
+    f = SegmentFeeder(str(tmp_path / "Wow"), subset="test", length=L, resident=resident)
     m = ntm.harness.build_model(W_D, max_delay_seconds=f.max_delay, fs=fs)
     xin, tgt, dt, _ = next(f.batches(len(f), "cuda"))
     want, _ = m.predict(xin, dt * fs)

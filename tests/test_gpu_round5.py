@@ -237,7 +237,8 @@ def test_bench_cli_workload_stage_times_and_cpu_port():
     import bench
     r = bench.cli_workload(torch.device("cuda", 0), True, n_seg=2, L=44100)
     assert r["unit"] == "samples/s" and r["value"] > 0 and abs(r["value"] - 2 * 44100 / r["command_s"]) < 1e-6 * r["value"]
-    assert set(r["stages_ms"]) == {"decode (WAV -> pinned host, side-car)", "h2d", "predict", "apply_delay", "ESR", "DCPreESR", "MultiSTFT"}
+    assert r["dataset_resident_on_device"] is True
+    assert set(r["stages_ms"]) == {"decode (WAV -> device, side-car)", "gather (device to device)", "predict", "apply_delay", "ESR", "DCPreESR", "MultiSTFT"}
     assert all(v > 0 for v in r["stages_ms"].values()) and r["bound_by"] in r["stages_ms"]
     assert 0 < r["gpu_busy_fraction_of_command"] <= r["gpu_busy_fraction_of_loss_loop"] <= 1.0
     cpu = r["cpu_baseline"]
@@ -329,3 +330,71 @@ def test_cli_fused_losses_path_matches_the_separate_passes(tmp_path, monkeypatch
     assert "predict_streamed_ms" in prof_a and "ESR_ms" in prof_a and "DCPreESR_ms" in prof_a
     assert "predict+ESR+DCPreESR_ms" in prof_b and "ESR_ms" not in prof_b and "DCPreESR_ms" not in prof_b and prof_b["h2d_ms"] > 0
     assert abs(a["ESR"] / b["ESR"] - 1) < 1e-9 and abs(a["DCPreESR"] / b["DCPreESR"] - 1) < 1e-5 and abs(a["MultiSTFT"] / b["MultiSTFT"] - 1) < 1e-9
+
+
+# ----------------------------------------------------------------------------- the device-resident decode
+@pytest.mark.parametrize("dtype", [np.int16, np.int32, np.uint8, np.float32, np.float64])
+@pytest.mark.parametrize("channels", [1, 2])
+def test_read_wav_device_equals_the_host_decode(tmp_path, monkeypatch, dtype, channels):
+    """feeder.read_wav_device (mapped file -> pinned staging chunks -> H2D -> de-interleave / convert / scale on the device)
+    gives the bits of the host decode for every PCM / float format, mono and stereo, across staging-chunk boundaries (the
+    chunk is shrunk to 4 kB here: 40 chunks, both staging pairs reused many times)."""
+    from scipy.io import wavfile
+    from ntm_amd import feeder as F
+    monkeypatch.setattr(F, "_STAGE_BYTES", 4096)
+    F._stage.clear()
+    rng = np.random.default_rng(11)
+    N = 20011
+    if dtype == np.uint8:
+        a = rng.integers(0, 256, (N, channels)).astype(dtype)
+    elif dtype in (np.int16, np.int32):
+        info = np.iinfo(dtype)
+        a = rng.integers(info.min, info.max, (N, channels), endpoint=True).astype(dtype)
+        a[0], a[1] = info.min, info.max
+    else:
+        a = rng.uniform(-1, 1, (N, channels)).astype(dtype)
+    path = str(tmp_path / "f.wav")
+    wavfile.write(path, 32000, a[:, 0] if channels == 1 else a)
+    want, fs0 = F.read_wav(path)
+    got, fs1 = F.read_wav_device(path)
+    F._stage.clear()                                              # (the 4 kB buffers must not outlive the test)
+    assert fs0 == fs1 == 32000 and got.is_cuda and got.dtype == torch.float32 and tuple(got.shape) == (channels, N) and got.is_contiguous()
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_resident_and_pinned_host_layouts_are_the_same_dataset(tmp_path):
+    """SegmentFeeder(resident=True) (the default on a HIP device: the decode is the H2D copy, the set lives in HBM) against
+    resident=False (pinned host, H2D per batch): items, statistics, batches and shards bit for bit -- int16 mono files of
+    uneven length, and a stereo float pair with a trajectory side-car."""
+    from scipy.io import wavfile
+    from ntm_amd.feeder import SegmentFeeder, write_sidecar
+    rng = np.random.default_rng(5)
+    d = tmp_path / "Set" / "Val"
+    d.mkdir(parents=True)
+    L = 2500
+    for i, n in enumerate((3 * L + 11, L, 2 * L + 999)):
+        x = (rng.uniform(-0.5, 0.5, n) * 32767).astype(np.int16)
+        wavfile.write(str(d / f"input_{i}_.wav"), 44100, x)
+        wavfile.write(str(d / f"target_{i}_.wav"), 44100, (0.25 * x).astype(np.int16))
+    N = 4 * L + 5
+    a = rng.uniform(-0.4, 0.4, (N, 2)).astype(np.float32)
+    wavfile.write(str(d / "input_7_.wav"), 44100, a)
+    wavfile.write(str(d / "target_7_.wav"), 44100, (0.5 * a).astype(np.float32))
+    traj = 0.003 + 0.001 * np.sin(np.arange(N) / 300.0)
+    peaks = np.arange(100, N - 100, 441)
+    meta = {"reconstruction_percentage": 0.0, "wiggle_percentage": 0.0}
+    write_sidecar(str(d / "trajectory_7_.npy"), peaks, peaks + 130, traj, meta, meta)
+    fa = SegmentFeeder(str(tmp_path / "Set"), subset="val", length=L, resident=False)
+    fb = SegmentFeeder(str(tmp_path / "Set"), subset="val", length=L)
+    assert fa.resident is False and fb.resident is True and len(fa) == len(fb) == 10
+    assert (fa.mean_delay, fa.max_delay, fa.min_delay, fa.fs, fa.minutes) == (fb.mean_delay, fb.max_delay, fb.min_delay, fb.fs, fb.minutes)
+    for i in range(len(fa)):
+        ia, ib = fa[i], fb[i]
+        assert not ib[0].is_cuda and torch.equal(ia[0], ib[0]) and torch.equal(ia[1], ib[1]) and ia[2]["input_name"] == ib[2]["input_name"]
+        if "delay_trajectory" in ia[2]:
+            assert torch.equal(ia[2]["delay_trajectory"], ib[2]["delay_trajectory"])
+    for bs in (4, 10):
+        for rank, world in ((0, 1), (1, 3)):
+            for (xa, ta, da, ma), (xb, tb, db, mb) in zip(fa.batches(bs, "cuda", rank, world), fb.batches(bs, "cuda", rank, world)):
+                assert torch.equal(xa, xb) and torch.equal(ta, tb) and ma == mb
+                assert (da is None) == (db is None) and (da is None or torch.equal(da, db))

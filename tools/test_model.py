@@ -205,7 +205,7 @@ def main(argv=None, profile=None):
     stages = StageTimes() if profile is not None else None
     if stages is not None:      # WAV decode into pinned host memory + trajectory side-cars (read, or analysed on first use)
         stages.host["decode_s"] = time.perf_counter() - t_decode
-        stages.host["segments"], stages.host["segment_length"] = len(feeder), feeder.length
+        stages.host["segments"], stages.host["segment_length"], stages.host["resident"] = len(feeder), feeder.length, feeder.resident
     if a.MAX_DELAY <= 0 and feeder.max_delay > 0:          # dataset.delay_analyzer.max_delay (code/test-model.py:223,323-324)
         a.MAX_DELAY = feeder.max_delay
 
