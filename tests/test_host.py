@@ -267,7 +267,7 @@ def test_recorded_bench_line_follows_the_contract():
     ow = d["other_workloads"]
     assert {"diffdel", "tcn", "gru_B8192", "gru_B16384", "gru_B32768"} <= set(ow) and "not a scaling curve" in ow["note"]
     for k, v in ow.items():
-        if k == "note":
+        if k in ("note", "cli"):
             continue
         assert v["kernel"] and 0 < v["kernel_ms"] <= v["ms_per_step"] * 1.001 and 0.3 < v["roofline"]["frac"] < 1.0
         assert v["checks"]["deterministic"] is True and len(v["checks"]["streams_checked"]) == 4
@@ -290,3 +290,22 @@ def test_recorded_bench_line_follows_the_contract():
     assert c["streams_vs_oracle"]["max_abs"] < 1e-5 and c["stream0_vs_reference_max_abs"] < 1e-5
     assert d["ms_per_step"] <= d["ms_per_step_no_warm_cache"] < 1.03 * d["ms_per_step"]
     assert d["roofline"]["traffic"] is not None and 1.0 <= d["roofline"]["traffic"] / (12.0 * seg * T) < 1.01
+    # round 5: the line names its point on BASELINE's "1/2/4/8 GPU" axis, keeps the facts inside the driver's 120-character cut,
+    # carries the record of the binary, the no-warm-cache value, the aggregate roofline, and the evaluation command end to end
+    assert d["metric"] == "audio samples/sec (44.1 kHz) GRU-HS[64], batch=4096x65536, 1 GPU" and len(d["config"]["workload"]) <= 120
+    assert "predict+ESR fused" in d["config"]["workload"] and "warm-cache on" in d["config"]["workload"]
+    assert abs(d["value_no_warm_cache"] - seg * T / (d["ms_per_step_no_warm_cache"] * 1e-3)) < 1e-6 * d["value"]
+    b = d["build"]
+    assert b["compiler"]["hip"] and b["runtime_hip"] and len(b["library_sha256"]) == 64
+    assert any("gru_mfma2_kernel<true, false, 0, 0, 16, false, true, false>" in k["kernel"] and k["scratch_bytes"] == 0 for k in b["kernels"])
+    g = r["aggregate"]
+    assert g["n_gpus"] == 1 and abs(g["frac"] - r["frac"]) < 1e-9 and len(g["kernel_ms_by_rank"]) == 1
+    cli = ow["cli"]
+    assert cli["unit"] == "samples/s" and abs(cli["value"] - 128 * 441000 / cli["command_s"]) < 1e-6 * cli["value"]
+    assert cli["bound_by"] in cli["stages_ms"] and all(v > 0 for v in cli["stages_ms"].values()) and len(cli["stages_ms"]) == 7
+    assert 0 < cli["gpu_busy_fraction_of_command"] <= cli["gpu_busy_fraction_of_loss_loop"] <= 1
+    assert cli["cpu_baseline"]["kind"] == "port" and cli["cpu_baseline"]["value"] > 0 and "scripts/test-model-loss.sh" in cli["reference_command"]
+    for k in ("ESR", "DCPreESR"):
+        assert abs(cli["losses"][k] / cli["cpu_baseline"]["losses"][k] - 1) < 2e-3          # (128 segments vs the first 2: close, not equal)
+    e = d["other_kernels"]["esr_dcpre_fused"]
+    assert e["esr_sums_identical"] is True and e["dcpre_sums_max_rel_diff"] < 2e-6 and e["saved_ms"] > 0.3
