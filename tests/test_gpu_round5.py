@@ -60,7 +60,7 @@ def test_g21_any_hidden_size_vs_reference(ntm, H):
         m.predict(x)
 
 
-@pytest.mark.parametrize("H", [1, 3, 5, 9, 24, 33, 48, 63, 65, 96, 127, 128, 129, 200, 300])
+@pytest.mark.parametrize("H", [1, 3, 5, 9, 24, 33, 48, 63, 65, 96, 127, 128, 129, 200, 300, 1024])
 @pytest.mark.parametrize("B,T", [(1, 1), (7, 63), (9, 64), (5, 65), (70, 129), (131, 400)])
 def test_any_hidden_size_ragged_vs_oracle(ntm, H, B, T):
     """Ragged batches (B not a multiple of the streams of a wavefront, T around the 64-sample tile), a non-zero initial
@@ -398,3 +398,35 @@ def test_resident_and_pinned_host_layouts_are_the_same_dataset(tmp_path):
             for (xa, ta, da, ma), (xb, tb, db, mb) in zip(fa.batches(bs, "cuda", rank, world), fb.batches(bs, "cuda", rank, world)):
                 assert torch.equal(xa, xb) and torch.equal(ta, tb) and ma == mb
                 assert (da is None) == (db is None) and (da is None or torch.equal(da, db))
+
+
+# ----------------------------------------------------------------------------- the N-rank line under the driver's launcher
+def test_bench_under_torch_distributed_run_two_ranks():
+    """The driver starts N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...`: the launcher's environment (TORCHELASTIC_*, GROUP_RANK, LOCAL_WORLD_SIZE,
+    OMP_NUM_THREADS=1) must not leak into rank 0's post-teardown legs -- the live counter passes are single-GPU child
+    commands, the CPU baseline uses the host's cores.  Two ranks share this box's GPU over gloo, 1040 x 65 536 per rank."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["NTM_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch", "1040", "--cpu-sample", "small", "--no-extra"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["backend"] == "gloo" and d["config"]["segments_total"] == 2080
+    assert d["metric"] == "audio samples/sec (44.1 kHz) GRU-HS[64], batch=1040x65536 per GPU, 2 GPU (weak scaling, 2080 segments)"
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == min(32, len(os.sched_getaffinity(0)))
+    assert d["checks"]["streams_vs_oracle"]["max_abs"] < TOL and d["checks"]["esr_sums_vs_oracle"]["max_rel"] < 1e-9
+    rf = d["roofline"]
+    assert rf["segments_in_launch"] == 1040 and rf["traffic"] is not None and "measured in this run" in rf["traffic_source"], rf["traffic_source"]
+    assert 1.0 <= rf["traffic"] / rf["algorithmic_bytes"] < 1.02
+    assert rf["aggregate"]["n_gpus"] == 2 and len(rf["aggregate"]["kernel_ms_by_rank"]) == 2 and "other_workloads" not in d

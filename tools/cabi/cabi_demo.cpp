@@ -224,12 +224,35 @@ int main(int argc, char **argv)
             worst = rel < 0 ? (-rel > worst ? -rel : worst) : (rel > worst ? rel : worst);
         }
     if (worst > 1e-12) { fprintf(stderr, "ntm_gru_forward_esr sums differ from ntm_esr_sums: %g\n", worst); return 9; }
+    // forward + BOTH time-domain losses in one call (ntm_gru_forward_losses) against ntm_esr_dcpre_sums on the same output
+    double *d1, *d2, *e3;
+    HIP_OK(hipMalloc(&d1, (size_t)B * 2 * sizeof(double)));
+    HIP_OK(hipMalloc(&d2, (size_t)B * 2 * sizeof(double)));
+    HIP_OK(hipMalloc(&e3, (size_t)B * 2 * sizeof(double)));
+    HIP_OK(hipMemset(dh2, 0, (size_t)B * 64 * sizeof(float)));
+    if (ntm_gru_forward_losses(w_ih, w_hh, b_ih, b_hh, w_o, b_o, NTM_HIDDEN, dx, dy2, B, T, T, T, dh2, dx, 0, e3, 0.995f, d1, stream) != NTM_OK) {
+        fprintf(stderr, "ntm_gru_forward_losses: %s\n", ntm_last_error()); return 10;
+    }
+    if (ntm_esr_dcpre_sums(dy2, dx, B, T, 0, 0.995f, d2, stream) != NTM_OK) return 11;
+    HIP_OK(hipStreamSynchronize(stream));
+    std::vector<double> w1((size_t)B * 2), w2((size_t)B * 2), w3((size_t)B * 2);
+    HIP_OK(hipMemcpy(w1.data(), d1, w1.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(w2.data(), d2, w2.size() * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(w3.data(), e3, w3.size() * sizeof(double), hipMemcpyDeviceToHost));
+    double worst_dc = 0.0;
+    for (size_t i = 0; i < w1.size(); ++i) {
+        const double rel = w2[i] != 0.0 ? (w1[i] - w2[i]) / w2[i] : w1[i];
+        worst_dc = rel < 0 ? (-rel > worst_dc ? -rel : worst_dc) : (rel > worst_dc ? rel : worst_dc);
+        if (w3[i] != v1[i]) { fprintf(stderr, "ntm_gru_forward_losses: ESR sums differ from ntm_gru_forward_esr's\n"); return 12; }
+    }
+    if (worst_dc > 1e-5) { fprintf(stderr, "ntm_gru_forward_losses DCPreESR sums differ from ntm_esr_dcpre_sums: %g\n", worst_dc); return 13; }
     HIP_OK(hipStreamSynchronize(stream));
     std::vector<float> y(x.size()), h((size_t)B * 64);
     HIP_OK(hipMemcpy(y.data(), dy, y.size() * sizeof(float), hipMemcpyDeviceToHost));
     HIP_OK(hipMemcpy(h.data(), dh, h.size() * sizeof(float), hipMemcpyDeviceToHost));
     FILE *f = fopen(argv[5], "wb"); fwrite(y.data(), sizeof(float), y.size(), f); fclose(f);
     f = fopen(argv[6], "wb"); fwrite(h.data(), sizeof(float), h.size(), f); fclose(f);
-    printf("ok B=%ld T=%ld forward_esr_vs_esr_sums_rel=%.1e last_error_after_refusal=\"%s\"\n", B, T, worst, ntm_last_error());
+    printf("ok B=%ld T=%ld forward_esr_vs_esr_sums_rel=%.1e forward_losses_dcpre_rel=%.1e last_error_after_refusal=\"%s\"\n", B, T, worst,
+           worst_dc, ntm_last_error());
     return 0;
 }
