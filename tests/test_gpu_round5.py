@@ -457,7 +457,7 @@ def test_full_size_cfg2_every_stream_against_the_oracle(ntm):
     sys.path.insert(0, ROOT)
     import bench
     B, T = 4096, 65536
-    threads = len(os.sched_getaffinity(0))
+    threads = max(1, min(32, len(os.sched_getaffinity(0))))      # (256 threads on the box were 2.7 x SLOWER than 32)
     x = bench.synth_input(B, T, torch.device("cuda", 0), seed=1234)
     m = ntm.harness.build_model(W_G)
     y = m.predict(x).cpu().numpy()[:, 0]
@@ -483,7 +483,7 @@ def test_full_size_cfg3_every_stream_against_the_oracle(ntm):
     sys.path.insert(0, ROOT)
     import bench
     B, T = 4096, 65536
-    threads = len(os.sched_getaffinity(0))
+    threads = max(1, min(32, len(os.sched_getaffinity(0))))      # (256 threads on the box were 2.7 x SLOWER than 32)
     dev0 = torch.device("cuda", 0)
     x = bench.synth_input(B, T, dev0, seed=1234)
     m = ntm.harness.build_model(W_D, max_delay_seconds=0.0335)
