@@ -32,7 +32,7 @@ extern "C" {
 #define NTM_EHIP (-2)    /* HIP runtime error (launch failed, no device)               */
 #define NTM_EDELAY (-3)  /* reserved for host-side delay-range checks                  */
 
-#define NTM_ABI_VERSION 8 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag.  3: the TCN scratch is padded (ntm_tcn_scratch_floats grew), dilation / length limits.  4: ntm_diffdel_gru_forward is ONE fused launch where the matrix-pipe kernel runs (+ ntm_diffdel_gru_forward_ex).  5: ntm_gru_forward_esr, ntm_diffdel_gru_forward_esr.  6: ntm_tcn_forward works through the batch in stream chunks, ntm_tcn_scratch_floats is bounded (<= 2.0e9 floats + padding for any B), ntm_tcn_chunk_streams; DiffDelGRU warm-up calls always take the two-pass form.  7: ntm_loss_scalars (+ include/ntm_rccl.h, libntm_rccl.so).  8: any hidden size in [1, NTM_MAX_HIDDEN]; ntm_gru_forward_losses (ESR + DCPreESR sums in the recurrent launch) */
+#define NTM_ABI_VERSION 8 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag.  3: the TCN scratch is padded (ntm_tcn_scratch_floats grew), dilation / length limits.  4: ntm_diffdel_gru_forward is ONE fused launch where the matrix-pipe kernel runs (+ ntm_diffdel_gru_forward_ex).  5: ntm_gru_forward_esr, ntm_diffdel_gru_forward_esr.  6: ntm_tcn_forward works through the batch in stream chunks, ntm_tcn_scratch_floats is bounded (<= 2.0e9 floats + padding for any B), ntm_tcn_chunk_streams; DiffDelGRU warm-up calls always take the two-pass form.  7: ntm_loss_scalars (+ include/ntm_rccl.h, libntm_rccl.so).  8: any hidden size in [1, NTM_MAX_HIDDEN]; ntm_gru_forward_losses / ntm_diffdel_gru_forward_losses (ESR + DCPreESR sums in the recurrent launch) */
 
 #define NTM_HIDDEN 64 /* hidden size of every shipped checkpoint (HS[64]): matrix-pipe and low-latency kernels.
                          Every other H in [1, NTM_MAX_HIDDEN] (the reference's `--HIDDEN_SIZE` is a free integer,
@@ -177,6 +177,16 @@ int ntm_diffdel_gru_forward_esr(const float *w_ih, const float *w_hh, const floa
                                 const float *d, float *y, float *pre_d, int64_t B, int64_t T,
                                 float *h_state, float *dl_state, int D, int32_t *err_flag,
                                 const float *target, int64_t skip, double *esr_out, void *stream);
+
+/* DiffDelRNN.forward + BOTH time-domain entries of the loss dict (ESR and DCPreESR of the DELAYED output, code/test-model.py:250-252,
+ * 353,386-388) in one call: as ntm_diffdel_gru_forward_esr, plus dcpre_R / dcpre_out [B,2] fp64 as in ntm_gru_forward_losses.  Where the
+ * fused step runs both pairs of sums come out of that ONE launch (accumulated in its delay stage); elsewhere the streaming passes follow. */
+int ntm_diffdel_gru_forward_losses(const float *w_ih, const float *w_hh, const float *b_ih,
+                                   const float *b_hh, const float *w_o, int H, const float *x,
+                                   const float *d, float *y, float *pre_d, int64_t B, int64_t T,
+                                   float *h_state, float *dl_state, int D, int32_t *err_flag,
+                                   const float *target, int64_t skip, double *esr_out, float dcpre_R,
+                                   double *dcpre_out, void *stream);
 
 /*
  * Per-stream sums for the ESR loss that follows the path in code/test-model.py:250-254,386-388

@@ -32,6 +32,8 @@ _SIGNATURES = {
     "ntm_diffdel_gru_forward_ex": (_int, [_vp] * 5 + [_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _int,
                                                       _vp, _int, _vp]),
     "ntm_diffdel_gru_forward_esr": (_int, [_vp] * 5 + [_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _i64, _vp, _vp]),
+    "ntm_diffdel_gru_forward_losses": (_int, [_vp] * 5 + [_int, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _int, _vp, _vp, _i64, _vp,
+                                              ctypes.c_float, _vp, _vp]),
     "ntm_esr_sums": (_int, [_vp, _vp, _i64, _i64, _i64, _int, _vp, _vp]),
     "ntm_esr_splits": (_int, [_i64, _i64, _i64]),
     "ntm_esr_dcpre_sums": (_int, [_vp, _vp, _i64, _i64, _i64, ctypes.c_float, _vp, _vp]),

@@ -158,7 +158,8 @@ __device__ __forceinline__ f32x4 pack_hl(const f16x4 hi, const f16x4 lo)
 //   As a separate pass on a side stream the 2 GB ESR kernel overlapped the NEXT step's launch and cost that launch
 //   0.37 ms -- its vector instructions take issue slots and datapath from the one wave per SIMD that feeds the matrix
 //   pipe; here it is ~25 instructions per thread and tile.
-// DCP = true (with ESR, GRU only): the DCPreESR entry of the loss dict (code/test-model.py:252) in the same flush.  Both
+// DCP = true (with ESR; for FUSE on the DELAYED output, in the fused delay stage): the DCPreESR entry of the loss dict
+//   (code/test-model.py:252) in the same flush.  Both
 //   signals e = t - y and t pass H(z) = (1 - z^-1)/(1 - R z^-1) from zero state at esr_skip and sum f(e)^2, sum f(t)^2 are
 //   accumulated per stream (ntm_esr_dcpre_sums' definition).  The 16 threads that flush a stream's tile are one DPP row:
 //   each runs its 4 samples from zero state, a 4-step row_shr scan with the constant ratios R^4, R^8, R^16, R^32 gives
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         esr_tile = tile;
     };
     // ---- DCP: the one-pole filter state of the stream's row (row-uniform), the fp64 sums of this thread's columns ----
-    static_assert(!DCP || (ESR && !FUSE), "the DCPreESR sums ride in the GRU kernel's ESR flush");
+    static_assert(!DCP || ESR, "the DCPreESR sums ride beside the ESR sums (GRU: in the y-tile flush; DiffDelGRU: in the fused delay stage)");
     double dcp_e = 0.0, dcp_t = 0.0;
     float dcp_ce = 0.0f, dcp_ct = 0.0f;                      // filter outputs at the last sample of the previous tile
     float dcp_le = 0.0f, dcp_lt = 0.0f;                      // filter inputs there
@@ -1000,6 +1001,9 @@ hipError_t launch_gru_mfma2_fused(const GruArgs &a, hipStream_t stream)
     const bool many = grid > (unsigned)device_cus();
     if (a.tgt) {        // + the ESR sums of the delayed output against a target, in the fused delay stage
         if (!a.esr_out || (a.esr_skip & 3) || a.esr_skip < 0 || a.warmup) return hipErrorInvalidValue;
+        if (a.dcp_out)  // ... + its DCPreESR sums
+            return many ? NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 4, true, true, true>), smem4)
+                        : NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 16, true, true, true>), smem16);
         return many ? NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 4, true, true>), smem4)
                     : NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 16, true, true>), smem16);
     }

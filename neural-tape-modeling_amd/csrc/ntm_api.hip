@@ -205,8 +205,9 @@ int ntm_delay_forward(const float *x, const float *d, float *y, int64_t B, int64
 static int diffdel_impl(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *w_o, int H,
                         const float *x, const float *d, float *y, float *pre_d, int64_t B, int64_t T, float *h_state,
                         float *dl_state, int D, int warmup, int32_t *err_flag, int mode, const float *target, int64_t skip,
-                        double *esr_out, void *stream)
+                        double *esr_out, void *stream, float dcp_R = 0.0f, double *dcp_out = nullptr)
 {
+    // dcp_out != NULL (ntm_diffdel_gru_forward_losses): also the DC-pre-emphasised sums, beside the ESR sums wherever those are formed
     // target != NULL: also the per-stream ESR sums of y against target over [skip, T) (ntm_diffdel_gru_forward_esr): inside the
     // fused launch where it runs and skip is a multiple of 4, by the streaming pass (one row per stream) everywhere else
     const bool esr_in_kernel = target && (skip & 3) == 0 && !warmup;
@@ -221,6 +222,7 @@ static int diffdel_impl(const float *w_ih, const float *w_hh, const float *b_ih,
         return fail(NTM_EINVAL, "ntm_diffdel_gru_forward: the fused kernel is compiled for hidden size 64 only");
     if (target && T == 0) {            // no samples: the sums are zero
         hipError_t ez = hipMemsetAsync(esr_out, 0, (size_t)B * 2 * sizeof(double), (hipStream_t)stream);
+        if (ez == hipSuccess && dcp_out) ez = hipMemsetAsync(dcp_out, 0, (size_t)B * 2 * sizeof(double), (hipStream_t)stream);
         return ez == hipSuccess ? NTM_OK : hip_fail(ez, "ntm_diffdel_gru_forward_esr");
     }
     // how many streams take the fused matrix-pipe kernel: all of them when forced; under AUTO the streams
@@ -257,6 +259,8 @@ static int diffdel_impl(const float *w_ih, const float *w_hh, const float *b_ih,
             a.tgt = target;
             a.esr_out = esr_out;
             a.esr_skip = skip;
+            a.dcp_out = dcp_out;
+            a.dcp_R = dcp_R;
         }
         hipError_t e = ntm::launch_gru_mfma2_fused(a, (hipStream_t)stream);
         if (e != hipSuccess) return hip_fail(e, "ntm_diffdel_gru_forward");
@@ -275,6 +279,7 @@ static int diffdel_impl(const float *w_ih, const float *w_hh, const float *b_ih,
             rc = ntm_delay_forward(pre_d, d, y, B, T, dl_state, D, warmup, err_flag, stream);
             if (rc != NTM_OK || !target) return rc;
             hipError_t ee = ntm::launch_esr(y, target, B, T, skip, 1, esr_out, (hipStream_t)stream);
+            if (ee == hipSuccess && dcp_out) ee = ntm::launch_esr_dcpre(y, target, B, T, skip, dcp_R, dcp_out, (hipStream_t)stream);
             return ee == hipSuccess ? NTM_OK : hip_fail(ee, "ntm_diffdel_gru_forward_esr");
         }
         // mixed: interpolate the remainder here, then ONE buffer update over all streams (it reads the flag both parts raise)
@@ -288,6 +293,8 @@ static int diffdel_impl(const float *w_ih, const float *w_hh, const float *b_ih,
         const int64_t from = esr_in_kernel ? fused : 0;
         if (from < B) {
             e = ntm::launch_esr(y + from * T, target + from * T, B - from, T, skip, 1, esr_out + 2 * from, (hipStream_t)stream);
+            if (e == hipSuccess && dcp_out)
+                e = ntm::launch_esr_dcpre(y + from * T, target + from * T, B - from, T, skip, dcp_R, dcp_out + 2 * from, (hipStream_t)stream);
             if (e != hipSuccess) return hip_fail(e, "ntm_diffdel_gru_forward_esr");
         }
     }
@@ -313,6 +320,20 @@ int ntm_diffdel_gru_forward_esr(const float *w_ih, const float *w_hh, const floa
     if (target == y || target == pre_d) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward_esr: target must not alias an output");
     return diffdel_impl(w_ih, w_hh, b_ih, b_hh, w_o, H, x, d, y, pre_d, B, T, h_state, dl_state, D, 0, err_flag, NTM_DIFFDEL_AUTO, target,
                         skip, esr_out, stream);
+}
+
+int ntm_diffdel_gru_forward_losses(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                                   const float *w_o, int H, const float *x, const float *d, float *y, float *pre_d,
+                                   int64_t B, int64_t T, float *h_state, float *dl_state, int D, int32_t *err_flag,
+                                   const float *target, int64_t skip, double *esr_out, float dcpre_R, double *dcpre_out, void *stream)
+{
+    if (!target || !esr_out || !dcpre_out) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward_losses: null pointer");
+    if (dcpre_out == esr_out) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward_losses: esr_out and dcpre_out must be distinct");
+    if (!(dcpre_R >= 0.0f && dcpre_R < 1.0f)) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward_losses: R must be in [0,1)");
+    if (skip < 0 || skip > T) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward_losses: bad skip");
+    if (target == y || target == pre_d) return fail(NTM_EINVAL, "ntm_diffdel_gru_forward_losses: target must not alias an output");
+    return diffdel_impl(w_ih, w_hh, b_ih, b_hh, w_o, H, x, d, y, pre_d, B, T, h_state, dl_state, D, 0, err_flag, NTM_DIFFDEL_AUTO, target,
+                        skip, esr_out, stream, dcpre_R, dcpre_out);
 }
 
 int ntm_diffdel_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,

@@ -507,8 +507,25 @@ class DiffDelRNN(_GRUHead):
         return y.view(B, 1, T), pre.view(B, 1, T), sums
 
     @torch.no_grad()
-    def predict_esr(self, input, d_traj, target, skip=0):
-        """predict(input, d_traj) + the ESR sums of the output against `target` over [skip, T)."""
+    def forward_losses(self, x, del_traj, target, skip=0, R=None):
+        """forward(x, del_traj) AND both time-domain entries of the loss dict for the delayed output against `target` over
+        samples [skip, T) (code/test-model.py:250-252,353,386-388) in one call: (y, pre_d, ESR sums (N,2) fp64, DCPreESR sums
+        (N,2) fp64).  ONE launch where the fused step runs (`delay_mode` / `kernel_variant` "auto", no skip connection); otherwise
+        forward() + the two streaming passes."""
+        R = DC_PRE_R if R is None else R
+        xbt = _as_bt(x, "DiffDelRNN.forward_losses")
+        dbt = _as_bt(del_traj, "DiffDelRNN.forward_losses")
+        tbt = _as_bt(target, "DiffDelRNN.forward_losses")
+        if dbt.shape != xbt.shape or tbt.shape != xbt.shape:
+            raise RuntimeError(f"shape mismatch: x {tuple(x.shape)} vs del_traj {tuple(del_traj.shape)} vs target {tuple(target.shape)}")
+        if self.kernel_variant != "auto" or self.skip or self.delay_mode != "auto":
+            y, pre = self.forward(x, del_traj)
+            return y, pre, esr_sums(y, target, skip), esr_dcpre_sums(y, target, skip, R)
+        B, T = xbt.shape
+        y, pre, (sums, dsums) = self._fused_step(xbt, dbt, False, None, tbt, int(skip), R)
+        return y.view(B, 1, T), pre.view(B, 1, T), sums, dsums
+
+    def _predict_with(self, fn, input):
         B = input.shape[0]
         self.initialize_hidden(1, self.max_delay)
         self.warm_start()
@@ -517,16 +534,27 @@ class DiffDelRNN(_GRUHead):
             self.diffdel.buffer = self.diffdel.buffer.expand(B, 1, -1).contiguous()
         deferred, self.diffdel.defer_check = self.diffdel.defer_check, True
         try:
-            out = self.forward_esr(input, d_traj, target, skip)
+            out = fn()
         finally:
             self.diffdel.defer_check = deferred
         if not deferred:
             self.diffdel.raise_if_violated()
         return out
 
-    def _fused_step(self, xbt, dbt, warmup, _events=None, tbt=None, skip=0):
+    @torch.no_grad()
+    def predict_esr(self, input, d_traj, target, skip=0):
+        """predict(input, d_traj) + the ESR sums of the output against `target` over [skip, T)."""
+        return self._predict_with(lambda: self.forward_esr(input, d_traj, target, skip), input)
+
+    @torch.no_grad()
+    def predict_losses(self, input, d_traj, target, skip=0, R=None):
+        """predict(input, d_traj) + the ESR and DCPreESR sums of the output against `target` over [skip, T)."""
+        return self._predict_with(lambda: self.forward_losses(input, d_traj, target, skip, R), input)
+
+    def _fused_step(self, xbt, dbt, warmup, _events=None, tbt=None, skip=0, dcp_R=None):
         """One C-ABI call for GRU + head + delay line (ntm_diffdel_gru_forward_ex); carries self.hidden and the delay
-        buffer exactly as the two calls do."""
+        buffer exactly as the two calls do.  With a target: + the ESR sums (ntm_diffdel_gru_forward_esr), with `dcp_R` also
+        the DCPreESR sums (ntm_diffdel_gru_forward_losses) of the delayed output."""
         B, T = xbt.shape
         dl = self.diffdel
         D = int(dl.max_delay)
@@ -549,6 +577,14 @@ class DiffDelRNN(_GRUHead):
                 ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0), ptr(self.output.weight),
                 self.hidden_size, ptr(xbt), ptr(dbt), ptr(y), ptr(pre), B, T, ptr(h), ptr(dl.buffer), D, int(bool(warmup)),
                 ptr(dl._err), _lib.DIFFDEL_MODES[self.delay_mode], _lib.current_stream())
+        elif dcp_R is not None:
+            sums = torch.empty(B, 2, device=xbt.device, dtype=torch.float64)
+            dsums = torch.empty(B, 2, device=xbt.device, dtype=torch.float64)
+            rc = _lib.lib().ntm_diffdel_gru_forward_losses(
+                ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0), ptr(self.output.weight),
+                self.hidden_size, ptr(xbt), ptr(dbt), ptr(y), ptr(pre), B, T, ptr(h), ptr(dl.buffer), D, ptr(dl._err),
+                ptr(tbt), int(skip), ptr(sums), float(dcp_R), ptr(dsums), _lib.current_stream())
+            sums = (sums, dsums)
         else:
             sums = torch.empty(B, 2, device=xbt.device, dtype=torch.float64)
             rc = _lib.lib().ntm_diffdel_gru_forward_esr(

@@ -501,3 +501,50 @@ def test_full_size_cfg3_every_stream_against_the_oracle(ntm):
                  worst_stream=int(per_p.argmax()), median_pre_d=float(np.median(per_p)), p99_pre_d=float(np.quantile(per_p, 0.99)),
                  state_worst=float(np.abs(h - ho).max()), buffer_worst=float(np.abs(buf - bo).max()), oracle_seconds=dt, oracle_threads=threads)
     assert per_y.max() < TOL and per_p.max() < TOL and np.abs(h - ho).max() < TOL and np.abs(buf - bo).max() < TOL
+
+
+# ----------------------------------------------------------------------------- DiffDelGRU: both time-domain losses out of the fused step
+@pytest.mark.parametrize("B,T,skip,MD", [(1040, 300, 64, 299), (1040, 4136, 1024, 1846), (4200, 700, 256, 299), (1040, 129, 128, 49),
+                                         (700, 300, 64, 299), (1040, 1000, 4, 1846), (1040, 300, 2, 299)])
+def test_diffdel_forward_losses_in_one_launch(ntm, B, T, skip, MD):
+    """DiffDelRNN.predict_losses (ntm_diffdel_gru_forward_losses): y and pre_d bit-identical to predict(), the ESR sums
+    bit-identical to predict_esr's, the DCPreESR sums of the DELAYED output against the streaming kernel on the same output
+    (2e-6 rel) and the oracle (2e-5 rel); trajectories with taps in the carried history and wow; B = 700 and skip = 2 take the
+    forward + streaming passes."""
+    rng = np.random.default_rng(B + T + skip + MD)
+    x = rng.uniform(-0.5, 0.5, (B, T)).astype(np.float32)
+    t = (0.6 * np.tanh(1.7 * np.roll(x, 7, axis=1)) + 0.04).astype(np.float32)
+    n = np.arange(T)
+    d = (0.5 * MD + 0.45 * MD * np.sin(n / 97.0 + rng.uniform(0, 6, (B, 1)))).astype(np.float32)
+    xd, td, dd = dev(x).unsqueeze(1), dev(t).unsqueeze(1), dev(d).unsqueeze(1)
+    m = ntm.DiffDelRNN(1, 64, 1, skip=False, max_delay=MD)
+    m.load_state_dict(ntm.weights.load_state_dict(W_D))
+    m = m.to("cuda").eval()
+    y, pre, s, dc = m.predict_losses(xd, dd, td, skip=skip)
+    h, buf = m.hidden.clone(), m.diffdel.buffer.clone()
+    y0, p0 = m.predict(xd, dd)
+    assert torch.equal(y, y0) and torch.equal(pre, p0) and torch.equal(m.hidden, h) and torch.equal(m.diffdel.buffer, buf)
+    y1, p1, s1 = m.predict_esr(xd, dd, td, skip=skip)
+    assert torch.equal(y1, y0) and torch.equal(s1, s)
+    want = ntm.esr_dcpre_sums(y0, td, skip).cpu().numpy()
+    got = dc.cpu().numpy()
+    assert np.isfinite(got).all() and (np.abs(got - want) / np.maximum(np.abs(want), 1e-30)).max() < 2e-6
+    rows = [0, 15, 16, B // 2, B - 1]
+    assert np.allclose(got[rows], oracle.esr_dcpre_sums(y0[rows, 0].cpu().numpy(), t[rows], skip), rtol=2e-5, atol=1e-12)
+
+
+def test_cli_diffdel_evaluation_is_one_launch_for_both_time_domain_losses(tmp_path, monkeypatch):
+    """The loss script's DiffDelGRU command (scripts/test-model-loss.sh:57-63 with MODEL = DiffDelGRU: --ADD_DELAY) now issues
+    predict + ESR + DCPreESR as ONE call; same losses as --KERNEL mfma2, which keeps the separate passes."""
+    from test_cli import _wow_dataset, cli_module
+    cli = cli_module("ntm_cli_r5c")
+    _wow_dataset(tmp_path, "Wow")
+    monkeypatch.chdir(tmp_path)
+    argv = ["--MODEL", "DiffDelGRU", "--WEIGHTS", W_D, "--DATASET_DIR", str(tmp_path / "Wow"), "--SUBSET", "Test", "--NO_SHUFFLE",
+            "--SEGMENT_LENGTH", "12000", "--ADD_DELAY", "--COMPUTE_LOSS", "--NO_EXAMPLE", "--NO_CACHE", "--INIT_LEN", "2048"]
+    pa, pb = {}, {}
+    a = cli.main(argv, profile=pa)
+    b = cli.main(argv + ["--KERNEL", "mfma2"], profile=pb)
+    assert "predict+ESR+DCPreESR_ms" in pa and "ESR_ms" not in pa and "predict_ms" in pb and "ESR_ms" in pb and "DCPreESR_ms" in pb
+    # (another GRU kernel underneath: the outputs differ in the last bits, the losses by far less than 1e-4)
+    assert abs(a["ESR"] / b["ESR"] - 1) < 1e-4 and abs(a["DCPreESR"] / b["DCPreESR"] - 1) < 1e-4 and abs(a["MultiSTFT"] / b["MultiSTFT"] - 1) < 1e-4

@@ -31,6 +31,7 @@ PINNED_VGPRS = {
     (0, 16, 1, 0, 0): 222, (0, 4, 1, 0, 0): 216,
     (0, 16, 1, 1, 0): 234, (0, 4, 1, 1, 0): 228,
     (0, 16, 0, 1, 1): 264, (0, 4, 0, 1, 1): 220,          # ESR + DCP: 256 VGPRs + 8 AGPRs (AGPR spills, no scratch)
+    (0, 16, 1, 1, 1): 251, (0, 4, 1, 1, 1): 243,          # FUSE + ESR + DCP
 }
 MFMA2_DYNAMIC_LDS = {16: 151680, 4: 53376}      # csrc/gru_mfma2.hip m2::smem_floats(YPN) * 4
 

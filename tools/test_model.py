@@ -297,8 +297,9 @@ def compute_loss(a, feeder, model, names, delay, is_dd, init_len, rank, world, s
 
         # plain GRU on whole-batch copies (--STREAM_CHUNK 0): predict + the ESR and DCPreESR sums in ONE launch where the
         # matrix-pipe kernel runs (RNN.predict_losses / ntm_gru_forward_losses); needs INIT_LEN to be a multiple of 4
-        fused_losses = (not is_dd and delay is None and not a.DEMODULATE and a.STREAM_CHUNK <= 0 and a.KERNEL == "auto"
-                        and init_len % 4 == 0)
+        # (the DiffDelGRU takes the batched path whenever --ADD_DELAY is given, as the loss script does: there too ONE launch)
+        fused_losses = (not a.DEMODULATE and a.KERNEL == "auto" and init_len % 4 == 0
+                        and ((not is_dd and delay is None and a.STREAM_CHUNK <= 0) or (is_dd and (a.ADD_DELAY or a.STREAM_CHUNK <= 0))))
 
         def batches():
             if a.DEMODULATE or a.ADD_DELAY or a.STREAM_CHUNK <= 0:
@@ -307,7 +308,11 @@ def compute_loss(a, feeder, model, names, delay, is_dd, init_len, rank, world, s
                     e = span("predict+ESR+DCPreESR" if fused_losses else "predict")
                     if is_dd:
                         assert dt is not None, "DiffDelGRU needs trajectory_<id>_*.npy side-cars"
-                        out, _ = model.predict(xin, dt * fs)
+                        if fused_losses:
+                            out, _, s_esr, s_dc = model.predict_losses(xin, dt * fs, tgt, skip=init_len)
+                            pre = {"ESR": s_esr, "DCPreESR": s_dc}
+                        else:
+                            out, _ = model.predict(xin, dt * fs)
                     elif fused_losses:
                         out, s_esr, s_dc = model.predict_losses(xin, tgt, skip=init_len)
                         pre = {"ESR": s_esr, "DCPreESR": s_dc}
