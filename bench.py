@@ -1050,6 +1050,20 @@ def main():
         # N > 1: rank 0 alone, after the process group is gone (the other ranks have left; nothing of this is timed)
         out["cpu_baseline"] = cpu_baseline(weights.W_GRU, small=a.cpu_sample == "small")
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        # the CPU sample's OWN shapes on the GPU (BASELINE configs[0]: 16 x 8192, what the reference runs on a CPU; the low-latency
+        # kernel at these batch sizes) -- like against like, beside the headline's 4096 x 65536 against 16 x 8192
+        same = {}
+        for key in out["cpu_baseline"]["shapes"]:
+            bs, ts = (int(v) for v in key.split("x"))
+            xs_ = synth_input(bs, ts, dev, seed=7)
+            ms_ = []
+            for i in range(4):
+                ev0.record(); model.predict(xs_); ev1.record(); torch.cuda.synchronize()
+                if i:
+                    ms_.append(ev0.elapsed_time(ev1))
+            same[key] = {"value": bs * ts / (float(np.mean(ms_)) * 1e-3), "unit": "samples/s", "ms": float(np.mean(ms_)),
+                         "speedup_vs_cpu_same_shape": bs * ts / (float(np.mean(ms_)) * 1e-3) / out["cpu_baseline"]["shapes"][key]["value"]}
+        out["cpu_baseline"]["same_shapes_on_the_gpu"] = same
         # CPU leg, outside the timed region: scattered streams of the LAST timed step's output (rank 0's rows) against the C
         # oracle over the whole sequence (the oracle is the checker here, never the thing measured)
         import oracle
