@@ -548,3 +548,35 @@ def test_cli_diffdel_evaluation_is_one_launch_for_both_time_domain_losses(tmp_pa
     assert "predict+ESR+DCPreESR_ms" in pa and "ESR_ms" not in pa and "predict_ms" in pb and "ESR_ms" in pb and "DCPreESR_ms" in pb
     # (another GRU kernel underneath: the outputs differ in the last bits, the losses by far less than 1e-4)
     assert abs(a["ESR"] / b["ESR"] - 1) < 1e-4 and abs(a["DCPreESR"] / b["DCPreESR"] - 1) < 1e-4 and abs(a["MultiSTFT"] / b["MultiSTFT"] - 1) < 1e-4
+
+
+def test_forward_losses_random_shapes_both_models(ntm):
+    """Seeded sweep over ragged shapes for the losses-in-the-launch kernels (GRU flush and fused DiffDelGRU delay stage):
+    T from 1 sample to a dozen tiles, skip anywhere a multiple of 4 up to T (incl. skip = T: empty sums), every result
+    against the streaming kernels on the same output (ESR bit for bit via predict_esr, DCPreESR 3e-6 rel)."""
+    rng = np.random.default_rng(505)
+    mg = ntm.harness.build_model(W_G)
+    md = ntm.DiffDelRNN(1, 64, 1, skip=False, max_delay=120)
+    md.load_state_dict(ntm.weights.load_state_dict(W_D))
+    md = md.to("cuda").eval()
+    B = 1040
+    for it in range(24):
+        T = int(rng.choice([1, 2, 3, 4, 5, 63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 300, 511, 640, 777]))
+        skip = 4 * int(rng.integers(0, T // 4 + 1))
+        x = rng.uniform(-0.5, 0.5, (B, T)).astype(np.float32)
+        t = (0.5 * np.tanh(2 * x) + 0.03).astype(np.float32)
+        xd, td = dev(x).unsqueeze(1), dev(t).unsqueeze(1)
+        y, s, dc = mg.predict_losses(xd, td, skip=skip)
+        y1, s1 = mg.predict_esr(xd, td, skip=skip)
+        want = ntm.esr_dcpre_sums(y1, td, skip)
+        assert torch.equal(y, y1) and torch.equal(s, s1), (T, skip)
+        tol = 3e-6 * want.abs() + 1e-12
+        assert bool(((dc - want).abs() <= tol).all()), ("gru", T, skip, float(((dc - want).abs() / want.abs().clamp_min(1e-30)).max()))
+        d = (60.0 + 55.0 * np.sin(np.arange(T) / 23.0 + rng.uniform(0, 6, (B, 1)))).astype(np.float32)
+        dd = dev(d).unsqueeze(1)
+        yy, pp, ss, dcc = md.predict_losses(xd, dd, td, skip=skip)
+        y2, p2, s2 = md.predict_esr(xd, dd, td, skip=skip)
+        want2 = ntm.esr_dcpre_sums(y2, td, skip)
+        assert torch.equal(yy, y2) and torch.equal(pp, p2) and torch.equal(ss, s2), (T, skip)
+        tol2 = 3e-6 * want2.abs() + 1e-12
+        assert bool(((dcc - want2).abs() <= tol2).all()), ("diffdel", T, skip, float(((dcc - want2).abs() / want2.abs().clamp_min(1e-30)).max()))
