@@ -15,6 +15,7 @@
 // Exact fp32 like the other exact kernels (different summation order: K split in four).
 #include "ntm_common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace ntm {
@@ -177,12 +178,151 @@ __global__ __launch_bounds__(256) void gru_lat_kernel(GruArgs a)
     if (a.h_state && w == 0) a.h_state[s * kH + u] = hold;
 }
 
+
+// ---- round 5: the same kernel with the step cut along UNITS between the waves and along K inside a quad of lanes ----------
+// gru_lat_kernel above needs TWO LDS round trips per step (partial sums out / in around the barrier, then the wave's private
+// copy of h out / in).  Here wave w owns units 16w .. 16w+15 outright: lane l = 4 ul + kq holds the K quarter kq of unit
+// 16w + ul for the three gates (48 weights, as before), the four quarters of a unit meet by two DPP quad_perm adds (every
+// lane of the quad gets the same bits), the quad evaluates the gates redundantly and lane kq = 0 publishes h_t -- ONE LDS
+// round trip per step: write h_t -> barrier -> four broadcast ds_read_b128 of the K quarter (h double-buffered by step parity,
+// so one barrier orders both the reads of h_{t-1} and the writes of h_t).  The head: each wave's partial over its 16 units is a
+// DPP wave sum of the PREVIOUS step's h (in registers at step start: the chain runs in the shadow of the h reads), parked by
+// step parity; the wave on duty (t mod 4) adds the four partials of the step before and stores y two samples behind the
+// recurrence.  Same arithmetic per unit as gru_lat_kernel except for the summation tree of the 64-term dot product.
+template <int PERM>
+__device__ __forceinline__ float quad_add(float v)
+{
+    const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), PERM, 0xf, 0xf, true);
+    return v + __builtin_bit_cast(float, o);
+}
+
+__global__ __launch_bounds__(256) void gru_lat2_kernel(GruArgs a)
+{
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) float hb[2][kH];            // h by step parity
+    __shared__ __attribute__((aligned(16))) float hpart[2][4];          // head partial of each wave, by step parity
+    __shared__ float xt[2][LT];
+    __shared__ float yt[2][LT];
+
+    const int tid = threadIdx.x, l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ul = l >> 2, kq = l & 3;
+    const int u = 16 * w + ul;                                          // this quad's hidden unit
+    const int64_t s = blockIdx.x;
+    const int64_t T = a.T;
+    const float *xs = a.x + s * a.xs;
+    float *ys = a.y + s * a.ys;
+
+    constexpr float SRZ = -LOG2E, SN = 2.0f * LOG2E;
+    f32x2 Wr[8], Wz[8], Wn[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float *pr = a.w_hh + (size_t)(0 * kH + u) * kH + 16 * kq + 2 * k;
+        const float *pz = a.w_hh + (size_t)(1 * kH + u) * kH + 16 * kq + 2 * k;
+        const float *pn = a.w_hh + (size_t)(2 * kH + u) * kH + 16 * kq + 2 * k;
+        Wr[k] = (f32x2){pr[0] * SRZ, pr[1] * SRZ};
+        Wz[k] = (f32x2){pz[0] * SRZ, pz[1] * SRZ};
+        Wn[k] = (f32x2){pn[0] * SN, pn[1] * SN};
+    }
+    const float wir = a.w_ih[u] * SRZ, wiz = a.w_ih[kH + u] * SRZ, win = a.w_ih[2 * kH + u] * SN;
+    const float br = (a.b_ih[u] + a.b_hh[u]) * SRZ, bz = (a.b_ih[kH + u] + a.b_hh[kH + u]) * SRZ;
+    const float bin_ = a.b_ih[2 * kH + u] * SN, bhn = a.b_hh[2 * kH + u] * SN;
+    const float bo = a.b_o ? a.b_o[0] : 0.0f;
+    const float wo = kq == 0 ? a.w_o[u] : 0.0f;                         // one lane of the quad carries the unit into the head
+    float hold = a.h_state ? a.h_state[s * kH + u] : 0.0f;
+
+    if (kq == 0) hb[0][u] = hold;
+    if (tid < 8) hpart[tid >> 2][tid & 3] = 0.0f;
+    if (tid < T) xt[0][tid] = xs[tid];
+    float xnext = (LT + tid < T) ? xs[LT + tid] : 0.0f;
+    __syncthreads();
+
+    // step t = tile + ph: hb[t & 1] holds h_{t-1}; tb = tile parity (of the x / y buffers)
+    auto step = [&](const int ph, const int tb) {
+        const int par = ph & 1;                                         // == t & 1 (tiles are 256 steps)
+        const f32x4 h0 = *(const f32x4 *)&hb[par][16 * kq + 0], h1 = *(const f32x4 *)&hb[par][16 * kq + 4];
+        const f32x4 h2 = *(const f32x4 *)&hb[par][16 * kq + 8], h3 = *(const f32x4 *)&hb[par][16 * kq + 12];
+        const float x = xt[tb][ph];
+        // in the shadow of those reads: the head partial of h_{t-1} (still in `hold`), and -- on the wave on duty -- y of
+        // sample t-2 from the four partials parked during step t-1
+        {
+            const float hp = wave_sum_lane63(wo * hold);
+            if (l == 63) hpart[par][w] = hp;
+            if ((ph & 3) == w && l == 0) {
+                const f32x4 q = *(const f32x4 *)&hpart[par ^ 1][0];
+                const float yv = ((q[0] + q[1]) + (q[2] + q[3])) + bo;
+                if (ph > 1) yt[tb][ph - 2] = yv; else yt[tb ^ 1][LT - 2 + ph] = yv;   // (t = 0, 1: a scratch write, see gru_lat_kernel)
+            }
+        }
+        const f32x2 hq[8] = {{h0[0], h0[1]}, {h0[2], h0[3]}, {h1[0], h1[1]}, {h1[2], h1[3]},
+                             {h2[0], h2[1]}, {h2[2], h2[3]}, {h3[0], h3[1]}, {h3[2], h3[3]}};
+        f32x2 ar0 = Wr[0] * hq[0], ar1 = Wr[1] * hq[1], az0 = Wz[0] * hq[0], az1 = Wz[1] * hq[1];
+        f32x2 an0 = Wn[0] * hq[0], an1 = Wn[1] * hq[1];
+#pragma unroll
+        for (int k = 2; k < 8; k += 2) {
+            ar0 = __builtin_elementwise_fma(Wr[k], hq[k], ar0); ar1 = __builtin_elementwise_fma(Wr[k + 1], hq[k + 1], ar1);
+            az0 = __builtin_elementwise_fma(Wz[k], hq[k], az0); az1 = __builtin_elementwise_fma(Wz[k + 1], hq[k + 1], az1);
+            an0 = __builtin_elementwise_fma(Wn[k], hq[k], an0); an1 = __builtin_elementwise_fma(Wn[k + 1], hq[k + 1], an1);
+        }
+        const f32x2 sr = ar0 + ar1, sz = az0 + az1, sn = an0 + an1;
+        // the unit's four K quarters: quad_perm [1,0,3,2] then [2,3,0,1] -- ((q0 + q1) + (q2 + q3)) in every lane of the quad
+        const float qr = quad_add<0x4E>(quad_add<0xB1>(sr[0] + sr[1]));
+        const float qz = quad_add<0x4E>(quad_add<0xB1>(sz[0] + sz[1]));
+        const float qn = quad_add<0x4E>(quad_add<0xB1>(sn[0] + sn[1]));
+        const float cr = __builtin_fmaf(wir, x, br), cz = __builtin_fmaf(wiz, x, bz), gi = __builtin_fmaf(win, x, bin_);
+        const float pr_ = cr + qr, pz_ = cz + qz, gh = bhn + qn;
+        const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pr_));
+        const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pz_));
+        const float en = __builtin_amdgcn_exp2f(__builtin_fmaf(r, gh, gi));
+        const float n = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + en), 1.0f);
+        hold = __builtin_fmaf(z, hold - n, n);
+        if (kq == 0) hb[par ^ 1][u] = hold;
+        __syncthreads();                                   // the step's only barrier
+    };
+
+    for (int64_t tile0 = 0; tile0 < T; tile0 += LT) {
+        const int ns = (int)((T - tile0) < LT ? (T - tile0) : LT);
+        const int tb = (int)((tile0 >> 8) & 1);
+        int ph = 0;
+        for (; ph < (ns < 3 ? ns : 3); ++ph) step(ph, tb);
+        if (ns > 2 && tile0 >= LT) ys[tile0 - LT + tid] = yt[tb ^ 1][tid];      // previous y tile is complete (its last two
+        for (; ph < (ns < 129 ? ns : 129); ++ph) step(ph, tb);                  // samples were stored during steps 0 and 1)
+        if (ns > 128) {
+            xt[tb ^ 1][tid] = xnext;
+            const int64_t nx = tile0 + 2 * LT + tid;
+            xnext = nx < T ? xs[nx] : 0.0f;
+        }
+        for (; ph < ns; ++ph) step(ph, tb);
+    }
+    // the last two samples: y_{T-2} from the partials parked during step T-1, y_{T-1} from the final state
+    if (T > 0) {
+        const float hp = wave_sum_lane63(wo * hold);
+        if (l == 63) hpart[(int)(T & 1)][w] = hp;
+        __syncthreads();
+        if (tid == 0) {
+            for (int64_t n = (T > 1 ? T - 2 : T - 1); n < T; ++n) {
+                const float *q = hpart[(int)((n + 1) & 1)];
+                yt[(int)((n >> 8) & 1)][(int)(n & (LT - 1))] = ((q[0] + q[1]) + (q[2] + q[3])) + bo;
+            }
+        }
+    }
+    __syncthreads();
+    const int64_t last0 = ((T - 1) >> 8) * LT;
+    if (T > 0) {
+        if (last0 + tid < T) ys[last0 + tid] = yt[(last0 >> 8) & 1][tid];
+        if (last0 >= LT && (T - 1 - last0) < 2) ys[last0 - LT + tid] = yt[((last0 >> 8) & 1) ^ 1][tid];
+    }
+    if (a.h_state && kq == 0) a.h_state[s * kH + u] = hold;
+}
+
 }   // namespace
 
 hipError_t launch_gru_lat(const GruArgs &a, hipStream_t stream)
 {
     if (a.B == 0) return hipSuccess;
-    hipLaunchKernelGGL(gru_lat_kernel, dim3((unsigned)a.B), dim3(256), 0, stream, a);
+    static const bool old_kernel = getenv("NTM_LAT_OLD") != nullptr;      // development A/B only
+    if (old_kernel) hipLaunchKernelGGL(gru_lat_kernel, dim3((unsigned)a.B), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(gru_lat2_kernel, dim3((unsigned)a.B), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
