@@ -185,10 +185,9 @@ __global__ __launch_bounds__(256) void gru_lat_kernel(GruArgs a)
 // 16w + ul for the three gates (48 weights, as before), the four quarters of a unit meet by two DPP quad_perm adds (every
 // lane of the quad gets the same bits), the quad evaluates the gates redundantly and lane kq = 0 publishes h_t -- ONE LDS
 // round trip per step: write h_t -> barrier -> four broadcast ds_read_b128 of the K quarter (h double-buffered by step parity,
-// so one barrier orders both the reads of h_{t-1} and the writes of h_t).  The head: each wave's partial over its 16 units is a
-// DPP wave sum of the PREVIOUS step's h (in registers at step start: the chain runs in the shadow of the h reads), parked by
-// step parity; the wave on duty (t mod 4) adds the four partials of the step before and stores y two samples behind the
-// recurrence.  Same arithmetic per unit as gru_lat_kernel except for the summation tree of the 64-term dot product.
+// so one barrier orders both the reads of h_{t-1} and the writes of h_t).  The head: the wave on duty (t mod 4) reads all 64
+// values of h_{t-1} from the same buffer (lane = unit) and sums w_o . h by DPP in the shadow of the K-quarter reads, one sample
+// behind the recurrence, as gru_lat_kernel does.  Same arithmetic per unit except for the summation tree of the dot product.
 template <int PERM>
 __device__ __forceinline__ float quad_add(float v)
 {
@@ -200,7 +199,6 @@ __global__ __launch_bounds__(256) void gru_lat2_kernel(GruArgs a)
 {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) float hb[2][kH];            // h by step parity
-    __shared__ __attribute__((aligned(16))) float hpart[2][4];          // head partial of each wave, by step parity
     __shared__ float xt[2][LT];
     __shared__ float yt[2][LT];
 
@@ -228,11 +226,10 @@ __global__ __launch_bounds__(256) void gru_lat2_kernel(GruArgs a)
     const float br = (a.b_ih[u] + a.b_hh[u]) * SRZ, bz = (a.b_ih[kH + u] + a.b_hh[kH + u]) * SRZ;
     const float bin_ = a.b_ih[2 * kH + u] * SN, bhn = a.b_hh[2 * kH + u] * SN;
     const float bo = a.b_o ? a.b_o[0] : 0.0f;
-    const float wo = kq == 0 ? a.w_o[u] : 0.0f;                         // one lane of the quad carries the unit into the head
+    const float wo_l = a.w_o[l];                                        // head weights by LANE: the wave on duty sums all 64 units
     float hold = a.h_state ? a.h_state[s * kH + u] : 0.0f;
 
     if (kq == 0) hb[0][u] = hold;
-    if (tid < 8) hpart[tid >> 2][tid & 3] = 0.0f;
     if (tid < T) xt[0][tid] = xs[tid];
     float xnext = (LT + tid < T) ? xs[LT + tid] : 0.0f;
     __syncthreads();
@@ -243,16 +240,11 @@ __global__ __launch_bounds__(256) void gru_lat2_kernel(GruArgs a)
         const f32x4 h0 = *(const f32x4 *)&hb[par][16 * kq + 0], h1 = *(const f32x4 *)&hb[par][16 * kq + 4];
         const f32x4 h2 = *(const f32x4 *)&hb[par][16 * kq + 8], h3 = *(const f32x4 *)&hb[par][16 * kq + 12];
         const float x = xt[tb][ph];
-        // in the shadow of those reads: the head partial of h_{t-1} (still in `hold`), and -- on the wave on duty -- y of
-        // sample t-2 from the four partials parked during step t-1
-        {
-            const float hp = wave_sum_lane63(wo * hold);
-            if (l == 63) hpart[par][w] = hp;
-            if ((ph & 3) == w && l == 0) {
-                const f32x4 q = *(const f32x4 *)&hpart[par ^ 1][0];
-                const float yv = ((q[0] + q[1]) + (q[2] + q[3])) + bo;
-                if (ph > 1) yt[tb][ph - 2] = yv; else yt[tb ^ 1][LT - 2 + ph] = yv;   // (t = 0, 1: a scratch write, see gru_lat_kernel)
-            }
+        // the head of sample t-1 on ONE wave per step (wave-uniform branch), from the same buffer: a fifth read, a DPP wave
+        // sum in the shadow of the reads above
+        if ((ph & 3) == w) {
+            const float yv = wave_sum_lane63(wo_l * hb[par][l]) + bo;
+            if (l == 63) { if (ph > 0) yt[tb][ph - 1] = yv; else yt[tb ^ 1][LT - 1] = yv; }
         }
         const f32x2 hq[8] = {{h0[0], h0[1]}, {h0[2], h0[3]}, {h1[0], h1[1]}, {h1[2], h1[3]},
                              {h2[0], h2[1]}, {h2[2], h2[3]}, {h3[0], h3[1]}, {h3[2], h3[3]}};
@@ -285,8 +277,8 @@ __global__ __launch_bounds__(256) void gru_lat2_kernel(GruArgs a)
         const int tb = (int)((tile0 >> 8) & 1);
         int ph = 0;
         for (; ph < (ns < 3 ? ns : 3); ++ph) step(ph, tb);
-        if (ns > 2 && tile0 >= LT) ys[tile0 - LT + tid] = yt[tb ^ 1][tid];      // previous y tile is complete (its last two
-        for (; ph < (ns < 129 ? ns : 129); ++ph) step(ph, tb);                  // samples were stored during steps 0 and 1)
+        if (ns > 2 && tile0 >= LT) ys[tile0 - LT + tid] = yt[tb ^ 1][tid];      // previous y tile is complete
+        for (; ph < (ns < 129 ? ns : 129); ++ph) step(ph, tb);
         if (ns > 128) {
             xt[tb ^ 1][tid] = xnext;
             const int64_t nx = tile0 + 2 * LT + tid;
@@ -294,17 +286,9 @@ __global__ __launch_bounds__(256) void gru_lat2_kernel(GruArgs a)
         }
         for (; ph < ns; ++ph) step(ph, tb);
     }
-    // the last two samples: y_{T-2} from the partials parked during step T-1, y_{T-1} from the final state
-    if (T > 0) {
-        const float hp = wave_sum_lane63(wo * hold);
-        if (l == 63) hpart[(int)(T & 1)][w] = hp;
-        __syncthreads();
-        if (tid == 0) {
-            for (int64_t n = (T > 1 ? T - 2 : T - 1); n < T; ++n) {
-                const float *q = hpart[(int)((n + 1) & 1)];
-                yt[(int)((n >> 8) & 1)][(int)(n & (LT - 1))] = ((q[0] + q[1]) + (q[2] + q[3])) + bo;
-            }
-        }
+    if (T > 0 && w == 0) {                                  // head of the last sample (h_{T-1} sits in hb[T & 1])
+        const float yv = wave_sum_lane63(wo_l * hb[(int)(T & 1)][l]) + bo;
+        if (l == 63) yt[(int)(((T - 1) >> 8) & 1)][(int)((T - 1) & (LT - 1))] = yv;
     }
     __syncthreads();
     const int64_t last0 = ((T - 1) >> 8) * LT;
