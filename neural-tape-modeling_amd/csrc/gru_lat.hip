@@ -55,7 +55,7 @@ __device__ __forceinline__ float quad_add(float v)
     return v + __builtin_bit_cast(float, o);
 }
 
-__global__ __launch_bounds__(256) void gru_lat_kernel(GruArgs a)
+__global__ __launch_bounds__(320) void gru_lat_kernel(GruArgs a)
 {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) float hb[2][kH];            // h by step parity
@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void gru_lat_kernel(GruArgs a)
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ul = l >> 2, kq = l & 3;
-    const int u = 16 * w + ul;                                          // this quad's hidden unit
+    const bool head_wave = w == 4;                                      // the fifth wave: head + nothing else (see the step)
+    const int u = 16 * (w & 3) + ul;                                    // this quad's hidden unit (the head wave: unused)
     const int64_t s = blockIdx.x;
     const int64_t T = a.T;
     const float *xs = a.x + s * a.xs;
@@ -89,9 +90,9 @@ __global__ __launch_bounds__(256) void gru_lat_kernel(GruArgs a)
     const float wo_l = a.w_o[l];                                        // head weights by LANE: the wave on duty sums all 64 units
     float hold = a.h_state ? a.h_state[s * kH + u] : 0.0f;
 
-    if (kq == 0) hb[0][u] = hold;
-    if (tid < T) xt[0][tid] = xs[tid];
-    float xnext = (LT + tid < T) ? xs[LT + tid] : 0.0f;
+    if (kq == 0 && !head_wave) hb[0][u] = hold;
+    if (tid < LT && tid < T) xt[0][tid] = xs[tid];
+    float xnext = (tid < LT && LT + tid < T) ? xs[LT + tid] : 0.0f;
     __syncthreads();
 
     // step t = tile + ph: hb[t & 1] holds h_{t-1}; tb = tile parity (of the x / y buffers)
@@ -99,15 +100,18 @@ __global__ __launch_bounds__(256) void gru_lat_kernel(GruArgs a)
     float *const hu_wr = &hb[0][u];                                     // (buffer 1: a compile-time + kH in the unrolled loop)
     auto step = [&](const int ph, const int tb, auto par_c) {
         constexpr int par = decltype(par_c)::value;                     // == t & 1 (tiles are 256 steps): compile time
+        if (head_wave) {
+            // the head of sample t-1 on a wave of its own: all 64 values of h_{t-1} from the exchange buffer (lane = unit), a DPP
+            // wave sum -- off the compute waves' critical path (as a duty rotating among them it held one of them up by the
+            // length of the DPP chain in EVERY step)
+            const float yv = wave_sum_lane63(wo_l * hb[par][l]) + bo;
+            if (l == 63) { if (ph > 0) yt[tb][ph - 1] = yv; else yt[tb ^ 1][LT - 1] = yv; }
+            __syncthreads();
+            return;
+        }
         const f32x4 h0 = *(const f32x4 *)(hq_rd + par * kH + 0), h1 = *(const f32x4 *)(hq_rd + par * kH + 4);
         const f32x4 h2 = *(const f32x4 *)(hq_rd + par * kH + 8), h3 = *(const f32x4 *)(hq_rd + par * kH + 12);
         const float x = xt[tb][ph];
-        // the head of sample t-1 on ONE wave per step (wave-uniform branch), from the same buffer: a fifth read, a DPP wave
-        // sum in the shadow of the reads above
-        if ((ph & 3) == w) {
-            const float yv = wave_sum_lane63(wo_l * hb[par][l]) + bo;
-            if (l == 63) { if (ph > 0) yt[tb][ph - 1] = yv; else yt[tb ^ 1][LT - 1] = yv; }
-        }
         const f32x2 hq[8] = {{h0[0], h0[1]}, {h0[2], h0[3]}, {h1[0], h1[1]}, {h1[2], h1[3]},
                              {h2[0], h2[1]}, {h2[2], h2[3]}, {h3[0], h3[1]}, {h3[2], h3[3]}};
         f32x2 ar0 = Wr[0] * hq[0], ar1 = Wr[1] * hq[1], az0 = Wz[0] * hq[0], az1 = Wz[1] * hq[1];
@@ -146,26 +150,26 @@ __global__ __launch_bounds__(256) void gru_lat_kernel(GruArgs a)
         const int ns = (int)((T - tile0) < LT ? (T - tile0) : LT);
         const int tb = (int)((tile0 >> 8) & 1);
         run(0, ns < 3 ? ns : 3, tb);
-        if (ns > 2 && tile0 >= LT) ys[tile0 - LT + tid] = yt[tb ^ 1][tid];      // previous y tile is complete
+        if (ns > 2 && tile0 >= LT && tid < LT) ys[tile0 - LT + tid] = yt[tb ^ 1][tid];      // previous y tile is complete
         run(3, ns < 129 ? ns : 129, tb);
-        if (ns > 128) {
+        if (ns > 128 && tid < LT) {
             xt[tb ^ 1][tid] = xnext;
             const int64_t nx = tile0 + 2 * LT + tid;
             xnext = nx < T ? xs[nx] : 0.0f;
         }
         run(129, ns, tb);
     }
-    if (T > 0 && w == 0) {                                  // head of the last sample (h_{T-1} sits in hb[T & 1])
+    if (T > 0 && head_wave) {                               // head of the last sample (h_{T-1} sits in hb[T & 1])
         const float yv = wave_sum_lane63(wo_l * hb[(int)(T & 1)][l]) + bo;
         if (l == 63) yt[(int)(((T - 1) >> 8) & 1)][(int)((T - 1) & (LT - 1))] = yv;
     }
     __syncthreads();
     const int64_t last0 = ((T - 1) >> 8) * LT;
-    if (T > 0) {
+    if (T > 0 && tid < LT) {
         if (last0 + tid < T) ys[last0 + tid] = yt[(last0 >> 8) & 1][tid];
         if (last0 >= LT && (T - 1 - last0) < 2) ys[last0 - LT + tid] = yt[((last0 >> 8) & 1) ^ 1][tid];
     }
-    if (a.h_state && kq == 0) a.h_state[s * kH + u] = hold;
+    if (a.h_state && kq == 0 && !head_wave) a.h_state[s * kH + u] = hold;
 }
 
 }   // namespace
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(256) void gru_lat_kernel(GruArgs a)
 hipError_t launch_gru_lat(const GruArgs &a, hipStream_t stream)
 {
     if (a.B == 0) return hipSuccess;
-    hipLaunchKernelGGL(gru_lat_kernel, dim3((unsigned)a.B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(gru_lat_kernel, dim3((unsigned)a.B), dim3(320), 0, stream, a);
     return hipGetLastError();
 }
 
