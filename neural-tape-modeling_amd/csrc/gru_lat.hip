@@ -46,7 +46,8 @@ __device__ __forceinline__ float wave_sum_lane63(float v)
 // round trip per step: write h_t -> barrier -> four broadcast ds_read_b128 of the K quarter (h double-buffered by step parity,
 // so one barrier orders both the reads of h_{t-1} and the writes of h_t).  The head: the wave on duty (t mod 4) reads all 64
 // values of h_{t-1} from the same buffer (lane = unit) and sums w_o . h by DPP in the shadow of the K-quarter reads, one sample
-// behind the recurrence.  316-322 ns per step for B <= 256 (342-344 before), 368 at B = 512 (426), 600 at B = 1024 (692).
+// behind the recurrence -- on a fifth wave of its own when the workgroup has a CU to itself.  242-246 ns per step for B <= 256
+// (342-344 before), 352 at B = 512 (426), 578 at B = 1024 (692).
 // x and y move in 256-sample tiles through LDS (coalesced global accesses); the tile housekeeping sits between runs of steps.
 template <int PERM>
 __device__ __forceinline__ float quad_add(float v)
@@ -55,7 +56,10 @@ __device__ __forceinline__ float quad_add(float v)
     return v + __builtin_bit_cast(float, o);
 }
 
-__global__ __launch_bounds__(320) void gru_lat_kernel(GruArgs a)
+// HEADW: a fifth wave does the head (B <= the number of CUs: a workgroup has a CU to itself); without it the head is a duty
+// that rotates among the four compute waves (more streams than CUs: a fifth wave per workgroup costs occupancy)
+template <bool HEADW>
+__global__ __launch_bounds__(HEADW ? 320 : 256) void gru_lat_kernel(GruArgs a)
 {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) float hb[2][kH];            // h by step parity
@@ -65,7 +69,7 @@ __global__ __launch_bounds__(320) void gru_lat_kernel(GruArgs a)
     const int tid = threadIdx.x, l = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ul = l >> 2, kq = l & 3;
-    const bool head_wave = w == 4;                                      // the fifth wave: head + nothing else (see the step)
+    const bool head_wave = HEADW && w == 4;                             // the fifth wave: head + nothing else (see the step)
     const int u = 16 * (w & 3) + ul;                                    // this quad's hidden unit (the head wave: unused)
     const int64_t s = blockIdx.x;
     const int64_t T = a.T;
@@ -100,18 +104,23 @@ __global__ __launch_bounds__(320) void gru_lat_kernel(GruArgs a)
     float *const hu_wr = &hb[0][u];                                     // (buffer 1: a compile-time + kH in the unrolled loop)
     auto step = [&](const int ph, const int tb, auto par_c) {
         constexpr int par = decltype(par_c)::value;                     // == t & 1 (tiles are 256 steps): compile time
-        if (head_wave) {
-            // the head of sample t-1 on a wave of its own: all 64 values of h_{t-1} from the exchange buffer (lane = unit), a DPP
-            // wave sum -- off the compute waves' critical path (as a duty rotating among them it held one of them up by the
-            // length of the DPP chain in EVERY step)
+        auto head = [&]() {              // y of sample t-1: all 64 values of h_{t-1} from the exchange buffer (lane = unit), DPP sum
             const float yv = wave_sum_lane63(wo_l * hb[par][l]) + bo;
             if (l == 63) { if (ph > 0) yt[tb][ph - 1] = yv; else yt[tb ^ 1][LT - 1] = yv; }
-            __syncthreads();
-            return;
+        };
+        if constexpr (HEADW) {
+            if (head_wave) {             // on a wave of its own, off the compute waves' critical path: 246 ns per step instead of 287
+                head();
+                __syncthreads();
+                return;
+            }
         }
         const f32x4 h0 = *(const f32x4 *)(hq_rd + par * kH + 0), h1 = *(const f32x4 *)(hq_rd + par * kH + 4);
         const f32x4 h2 = *(const f32x4 *)(hq_rd + par * kH + 8), h3 = *(const f32x4 *)(hq_rd + par * kH + 12);
         const float x = xt[tb][ph];
+        if constexpr (!HEADW) {          // as a duty that rotates among the compute waves, in the shadow of the reads above
+            if ((ph & 3) == w) head();
+        }
         const f32x2 hq[8] = {{h0[0], h0[1]}, {h0[2], h0[3]}, {h1[0], h1[1]}, {h1[2], h1[3]},
                              {h2[0], h2[1]}, {h2[2], h2[3]}, {h3[0], h3[1]}, {h3[2], h3[3]}};
         f32x2 ar0 = Wr[0] * hq[0], ar1 = Wr[1] * hq[1], az0 = Wz[0] * hq[0], az1 = Wz[1] * hq[1];
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(320) void gru_lat_kernel(GruArgs a)
         }
         run(129, ns, tb);
     }
-    if (T > 0 && head_wave) {                               // head of the last sample (h_{T-1} sits in hb[T & 1])
+    if (T > 0 && (HEADW ? head_wave : w == 0)) {            // head of the last sample (h_{T-1} sits in hb[T & 1])
         const float yv = wave_sum_lane63(wo_l * hb[(int)(T & 1)][l]) + bo;
         if (l == 63) yt[(int)(((T - 1) >> 8) & 1)][(int)((T - 1) & (LT - 1))] = yv;
     }
@@ -177,7 +186,8 @@ __global__ __launch_bounds__(320) void gru_lat_kernel(GruArgs a)
 hipError_t launch_gru_lat(const GruArgs &a, hipStream_t stream)
 {
     if (a.B == 0) return hipSuccess;
-    hipLaunchKernelGGL(gru_lat_kernel, dim3((unsigned)a.B), dim3(320), 0, stream, a);
+    if (a.B <= device_cus()) hipLaunchKernelGGL(gru_lat_kernel<true>, dim3((unsigned)a.B), dim3(320), 0, stream, a);
+    else hipLaunchKernelGGL(gru_lat_kernel<false>, dim3((unsigned)a.B), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
