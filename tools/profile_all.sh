@@ -30,5 +30,6 @@ for n in $NAMES; do
         tape)    prof tape tools/tape_probe.py ;;
         losses)  prof losses tools/loss_probe.py ;;
         demod)   prof demod tools/demod_probe.py ;;
+        cli)     prof cli tools/other_leg.py cli 128 ;;
     esac
 done
