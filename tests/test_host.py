@@ -222,6 +222,17 @@ def test_step_barrier_wait_count_matches_the_disassembly():
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
+def test_no_dpp_instruction_can_run_under_a_partial_exec_mask():
+    """tools/check_dpp_exec.py: a forward data-flow over the control-flow graph of every kernel that uses cross-lane DPP operations
+    (the DCPreESR scan of the recurrent kernel's flush, the quad / wave sums of the low-latency and small-H kernels) proves that none
+    of them can execute while a divergent region is open.  Round 5 lost a result to exactly that: hipcc sank a DPP move written
+    under a select into the branch, where lanes read EXEC-disabled neighbours (the checker flags that build: verified by hand)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_exec.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "none under a partial EXEC mask: ok" in r.stdout, r.stderr[-3000:]
+
+
 def test_product_kernels_use_no_scratch_and_keep_their_register_budget():
     """tools/kernel_resources.py --check on the built libntm.so: the code objects' own metadata must show no scratch and no
     VGPR spill for ANY kernel, and the product instantiations of the recurrent kernel must not exceed the VGPR counts of the
