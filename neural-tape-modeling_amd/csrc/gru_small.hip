@@ -174,7 +174,8 @@ __global__ __launch_bounds__(256) void gru_wide_kernel(GruArgs a)
     __shared__ float xt[2][TT];
     __shared__ float gh[REGW ? 1 : 3 * HMAX];      // REGW = false: W_hh . h of the step, all three gates
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform BY CONSTRUCTION: the row loop below carries DPP sums (tools/check_dpp_exec.py)
+    // (scalar: the row loop of the REGW = false step carries DPP sums and must not be exec-masked, tools/check_dpp_exec.py)
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int H = a.H;
     const int64_t b = blockIdx.x, T = a.T;
     const float bo = a.b_o ? a.b_o[0] : 0.0f;
