@@ -123,12 +123,8 @@ __global__ __launch_bounds__(HEADW ? 320 : 256) void gru_lat_kernel(GruArgs a)
         }
         const f32x2 hq[8] = {{h0[0], h0[1]}, {h0[2], h0[3]}, {h1[0], h1[1]}, {h1[2], h1[3]},
                              {h2[0], h2[1]}, {h2[2], h2[3]}, {h3[0], h3[1]}, {h3[2], h3[3]}};
-        // the input terms ride in the accumulators of the quad's lane 0 (one dependent add less behind the reduction)
-        const float cr = __builtin_fmaf(wir, x, br), cz = __builtin_fmaf(wiz, x, bz), gi = __builtin_fmaf(win, x, bin_);
-        const f32x2 ir = {kq == 0 ? cr : 0.0f, 0.0f}, iz = {kq == 0 ? cz : 0.0f, 0.0f}, in_ = {kq == 0 ? bhn : 0.0f, 0.0f};
-        f32x2 ar0 = __builtin_elementwise_fma(Wr[0], hq[0], ir), ar1 = Wr[1] * hq[1];
-        f32x2 az0 = __builtin_elementwise_fma(Wz[0], hq[0], iz), az1 = Wz[1] * hq[1];
-        f32x2 an0 = __builtin_elementwise_fma(Wn[0], hq[0], in_), an1 = Wn[1] * hq[1];
+        f32x2 ar0 = Wr[0] * hq[0], ar1 = Wr[1] * hq[1], az0 = Wz[0] * hq[0], az1 = Wz[1] * hq[1];
+        f32x2 an0 = Wn[0] * hq[0], an1 = Wn[1] * hq[1];
 #pragma unroll
         for (int k = 2; k < 8; k += 2) {
             ar0 = __builtin_elementwise_fma(Wr[k], hq[k], ar0); ar1 = __builtin_elementwise_fma(Wr[k + 1], hq[k + 1], ar1);
@@ -137,18 +133,16 @@ __global__ __launch_bounds__(HEADW ? 320 : 256) void gru_lat_kernel(GruArgs a)
         }
         const f32x2 sr = ar0 + ar1, sz = az0 + az1, sn = an0 + an1;
         // the unit's four K quarters: quad_perm [1,0,3,2] then [2,3,0,1] -- ((q0 + q1) + (q2 + q3)) in every lane of the quad
-        const float pr_ = quad_add<0x4E>(quad_add<0xB1>(sr[0] + sr[1]));
-        const float pz_ = quad_add<0x4E>(quad_add<0xB1>(sz[0] + sz[1]));
-        const float gh = quad_add<0x4E>(quad_add<0xB1>(sn[0] + sn[1]));
-        // gates on pre-scaled arguments: r, z = 1/(1 + 2^p); n = 1 - 2 q, q = 1/(1 + 2^(gi + r gh)).  The blend
-        // h' = n + z (h - n) = [z h + (1 - z)] - 2 (1 - z) q is arranged so that ONE fma follows the last reciprocal: z is ready
-        // long before q (its chain does not pass through r)
-        const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pz_));
-        const float omz = 1.0f - z;
-        const float blend_a = __builtin_fmaf(z, hold, omz), blend_b = -2.0f * omz;
+        const float qr = quad_add<0x4E>(quad_add<0xB1>(sr[0] + sr[1]));
+        const float qz = quad_add<0x4E>(quad_add<0xB1>(sz[0] + sz[1]));
+        const float qn = quad_add<0x4E>(quad_add<0xB1>(sn[0] + sn[1]));
+        const float cr = __builtin_fmaf(wir, x, br), cz = __builtin_fmaf(wiz, x, bz), gi = __builtin_fmaf(win, x, bin_);
+        const float pr_ = cr + qr, pz_ = cz + qz, gh = bhn + qn;
         const float r = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pr_));
-        const float q = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__builtin_fmaf(r, gh, gi)));
-        hold = __builtin_fmaf(blend_b, q, blend_a);
+        const float z = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(pz_));
+        const float en = __builtin_amdgcn_exp2f(__builtin_fmaf(r, gh, gi));
+        const float n = __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + en), 1.0f);
+        hold = __builtin_fmaf(z, hold - n, n);
         hu_wr[(par ^ 1) * kH] = hold;                      // all four lanes of the quad store the same bits to the same word
         __syncthreads();                                   // the step's only barrier
     };
