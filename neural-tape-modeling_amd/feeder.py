@@ -275,6 +275,21 @@ class SegmentFeeder:
         for idx, (ifile, tfile) in enumerate(zip(self.input_files, self.target_files)):
             if not input_only and _file_id(ifile) != _file_id(tfile):
                 raise RuntimeError(f"Found non-matching file ids: {_file_id(ifile)} != {_file_id(tfile)}! Check dataset.")
+            # the side-car (the reference's pickled fp64 trajectory: ~90 ms to unpickle per 450 MB) loads on a worker thread
+            # while the audio is decoded (file reads, large copies and the device work all release the GIL)
+            sidecar = sidecar_path(ifile)
+            side = {}
+            loader = None
+            if os.path.exists(sidecar):
+                import threading
+
+                def _load(path=sidecar, out=side):
+                    try:
+                        out["d"] = load_trajectory(path)
+                    except Exception as e:           # re-raised on the constructing thread below
+                        out["error"] = e
+                loader = threading.Thread(target=_load, daemon=True)
+                loader.start()
             x, fs = read_wav_device(ifile) if self.resident else read_wav(ifile)
             self.fs = self.fs or fs
             if fs != self.fs:
@@ -291,8 +306,12 @@ class SegmentFeeder:
                     raise RuntimeError("Found potentially corrupt file!")
             # the side-car sits next to its input file under the input's own name (code/utilities/utilities.py:273-275):
             # with subset "full" equal ids in Train/ Val/ Test/ must not pick up each other's trajectories
-            sidecar = sidecar_path(ifile)
-            d = load_trajectory(sidecar) if os.path.exists(sidecar) else None
+            d = None
+            if loader is not None:
+                loader.join()
+                if "error" in side:
+                    raise side["error"]
+                d = side["d"]
             if d is None and analyze and t is not None and x.shape[0] > 1 and t.shape[0] > 1:
                 # stereo pair without a side-car: analyse the pilot channels as DelayAnalyzer does on first use
                 # (code/utilities/utilities.py:306-335) and cache the result next to the audio in its format
