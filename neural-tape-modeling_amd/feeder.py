@@ -59,28 +59,16 @@ _STAGE_BYTES = 64 << 20
 _stage = {}          # device index -> two pinned staging buffers + the events that guard their reuse
 
 
-def read_wav_device(path, device="cuda"):
-    """-> (float32 [C, N] tensor ON THE DEVICE, fs), the same values as read_wav.  The decode IS the host-to-device copy:
-    the file is memory-mapped, its interleaved frames go through two pinned 64 MB staging buffers (the one host pass: page
-    cache -> pinned) and over PCIe as they are, and the de-interleave, the conversion to fp32 and the PCM scaling run on the
-    device -- a 450 MB stereo float32 file takes 14 ms (tools/decode_probe.py) where wavfile.read + the numpy transpose +
-    pinning took 115 on the host.  With 288 GB of HBM a whole evaluation set lives on the device; SegmentFeeder falls back
-    to the pinned-host layout when it does not fit."""
-    dev = torch.device(device)
-    if dev.index is None:
-        dev = torch.device("cuda", torch.cuda.current_device())
-    try:
-        fs, a = wavfile.read(path, mmap=True)
-    except (ValueError, OSError):                    # formats scipy cannot map (24-bit PCM: it repacks the samples)
-        fs, a = wavfile.read(path)
-    if a.ndim == 1:
-        a = a[:, None]
+_TORCH_DT = {np.dtype(np.int16): torch.int16, np.dtype(np.int32): torch.int32, np.dtype(np.uint8): torch.uint8,
+             np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}
+
+
+def upload_frames(a, dev):
+    """Interleaved frames a [N, C] (numpy, possibly memory-mapped; a dtype of _TORCH_DT) -> float32 [C, N] on `dev`: chunks of
+    64 MB through two reused pinned staging buffers (the one host pass), H2D as they are, de-interleave + conversion on the
+    device.  Asynchronous on the current stream except for the reuse of a staging buffer."""
     N, C = a.shape
-    tdt = {np.dtype(np.int16): torch.int16, np.dtype(np.int32): torch.int32, np.dtype(np.uint8): torch.uint8,
-           np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}.get(a.dtype)
-    if tdt is None or not a.dtype.isnative:
-        x, fs = read_wav(path)
-        return torch.from_numpy(x).to(dev), fs
+    tdt = _TORCH_DT[a.dtype]
     st = _stage.get(dev.index)
     if st is None:
         st = _stage[dev.index] = {"host": [torch.empty(_STAGE_BYTES, dtype=torch.uint8).pin_memory() for _ in range(2)],
@@ -99,6 +87,32 @@ def read_wav_device(path, device="cuda"):
             dv.copy_(hv, non_blocking=True)
             out[:, f0:f0 + n].copy_(dv.view(tdt).view(n, C).t())      # de-interleave + convert on the device
             st["ev"][b].record()
+    return out
+
+
+def read_wav_device(path, device="cuda"):
+    """-> (float32 [C, N] tensor ON THE DEVICE, fs), the same values as read_wav.  The decode IS the host-to-device copy:
+    the file is memory-mapped, its interleaved frames go through two pinned 64 MB staging buffers (the one host pass: page
+    cache -> pinned) and over PCIe as they are, and the de-interleave, the conversion to fp32 and the PCM scaling run on the
+    device -- a 450 MB stereo float32 file takes 14 ms (tools/decode_probe.py) where wavfile.read + the numpy transpose +
+    pinning took 115 on the host.  With 288 GB of HBM a whole evaluation set lives on the device; SegmentFeeder falls back
+    to the pinned-host layout when it does not fit."""
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    try:
+        fs, a = wavfile.read(path, mmap=True)
+    except (ValueError, OSError):                    # formats scipy cannot map (24-bit PCM: it repacks the samples)
+        fs, a = wavfile.read(path)
+    if a.ndim == 1:
+        a = a[:, None]
+    N, C = a.shape
+    tdt = _TORCH_DT.get(a.dtype)
+    if tdt is None or not a.dtype.isnative:
+        x, fs = read_wav(path)
+        return torch.from_numpy(x).to(dev), fs
+    out = upload_frames(a, dev)
+    with torch.cuda.device(dev):
         if a.dtype in _PCM:                          # the same fp32 operations as read_wav: exact (powers of two)
             off, div = _PCM[a.dtype]
             if off:
@@ -333,8 +347,10 @@ class SegmentFeeder:
             # device is present: a batch then goes to the device as a few large DMA copies straight from here (no per-batch
             # staging copy on the host)
             if d is not None:
-                t32 = tr.to(torch.float32)[None, :].contiguous()
-                d["traj_f32"] = t32.pin_memory().to(x.device, non_blocking=True) if self.resident else self._host(t32.numpy())
+                if self.resident:    # fp64 -> fp32 on the device, through the decode's own staging buffers (exactly as rounded on the host)
+                    d["traj_f32"] = upload_frames(np.ascontiguousarray(d["delay_trajectory"]).reshape(-1, 1), x.device)
+                else:
+                    d["traj_f32"] = self._host(tr.to(torch.float32)[None, :].contiguous().numpy())
             self._audio.append((self._host(x), None if t is None else self._host(t), d))
             start = int(self.sync * self.fs)
             for n_chunk in range((num_frames - start) // self.length):
