@@ -18,11 +18,12 @@ def T(name, fn, reps=3):
         best = dt if best is None else min(best, dt)
     out[name + "_ms"] = best
     return r
-T("SegmentFeeder", lambda: F.SegmentFeeder(ds, subset="Test", length=441000, shuffle=False))
+T("SegmentFeeder_resident", lambda: F.SegmentFeeder(ds, subset="Test", length=441000, shuffle=False), reps=5)
+T("SegmentFeeder_pinned_host", lambda: F.SegmentFeeder(ds, subset="Test", length=441000, shuffle=False, resident=False))
 ifile = os.path.join(ds, "Test", "input_1_.wav")
 side = os.path.join(ds, "Test", "trajectory_1_.npy")
-T("read_wav_pin", lambda: F.read_wav(ifile, pin=True))
-T("read_wav_numpy", lambda: F.read_wav(ifile))
+T("read_wav_device", lambda: (F.read_wav_device(ifile), torch.cuda.synchronize()))
+T("read_wav_host", lambda: F.read_wav(ifile))
 fs, mm = wavfile.read(ifile, mmap=True)
 with warnings.catch_warnings():
     warnings.simplefilter("ignore")
@@ -40,5 +41,7 @@ T("np_mean", lambda: np.mean(tj)); T("np_max", lambda: np.max(tj))
 tt = torch.from_numpy(tj)
 T("torch_max", lambda: tt.max()); T("torch_to_f32", lambda: tt.to(torch.float32))
 T("np_to_f32", lambda: np.ascontiguousarray(tj, np.float32))
+T("traj_pin_and_h2d", lambda: (tt.to(torch.float32)[None, :].contiguous().pin_memory().to("cuda", non_blocking=True), torch.cuda.synchronize()))
+T("traj_upload_frames", lambda: (F.upload_frames(tj.reshape(-1, 1), torch.device("cuda", 0)), torch.cuda.synchronize()))
 print(json.dumps(out))
 shutil.rmtree(tmp, ignore_errors=True)
