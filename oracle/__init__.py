@@ -45,6 +45,8 @@ def lib():
         _LIB.ntmo_gru_forward.argtypes = [_f32p] * 6 + [ctypes.c_int, _f32p, _f32p,
                                                         ctypes.c_int64, ctypes.c_int64, _f32p]
         _LIB.ntmo_gru_forward_mt.argtypes = _LIB.ntmo_gru_forward.argtypes + [ctypes.c_int]
+        _LIB.ntmo_gru_forward_f64_mt.argtypes = [_f32p] * 6 + [ctypes.c_int, _f32p, _f64p, ctypes.c_int64, ctypes.c_int64, _f64p, ctypes.c_int]
+        _LIB.ntmo_delay_forward_f64.argtypes = [_f64p, _f32p, _f64p, ctypes.c_int64, ctypes.c_int64, _f64p, ctypes.c_int, ctypes.c_int]
         _LIB.ntmo_delay_forward.argtypes = [_f32p, _f32p, _f32p, ctypes.c_int64, ctypes.c_int64,
                                             _f32p, ctypes.c_int, ctypes.c_int]
         _LIB.ntmo_esr_sums.argtypes = [_f32p, _f32p, ctypes.c_int64, ctypes.c_int64,
@@ -143,6 +145,55 @@ def diffdel_predict(w, x, d, max_delay, threads=1):
     z = np.zeros((1, 1024), np.float32)
     _, _, h1, b1 = diffdel_forward(w, z, z, None, np.zeros((1, D), np.float32))
     return diffdel_forward(w, x, d, np.repeat(h1, B, 0), np.repeat(b1, B, 0), threads=threads)
+
+
+def _pd(a):
+    return a.ctypes.data_as(_f64p)
+
+
+def gru_forward_f64(w, x, h=None, threads=1):
+    """fp64 mode of gru_forward (ntm_oracle.c gru_stream_f64): fp32 parameters and input, double state / accumulators / gates.
+    x [B,T] fp32 -> (y [B,T] float64, h_out [B,H] float64).  A yardstick for rounding, not a parity target."""
+    x = _c(x)
+    B, T = x.shape
+    h = np.zeros((B, w.H), np.float64) if h is None else np.ascontiguousarray(h, np.float64).copy()
+    y = np.empty((B, T), np.float64)
+    assert lib().ntmo_gru_forward_f64_mt(_p(w.w_ih), _p(w.w_hh), _p(w.b_ih), _p(w.b_hh), _p(w.w_o), _p(w.b_o), w.H, _p(x), _pd(y),
+                                         B, T, _pd(h), max(1, int(threads))) == 0
+    return y, h
+
+
+def gru_predict_f64(w, x, threads=1):
+    """gru_predict in fp64 mode (warm state from 1024 zero samples, also in double)."""
+    x = _c(x)
+    _, h1 = gru_forward_f64(w, np.zeros((1, 1024), np.float32))
+    return gru_forward_f64(w, x, np.repeat(h1, x.shape[0], 0), threads)
+
+
+def delay_forward_f64(x, d, buf, warmup=False):
+    x = np.ascontiguousarray(x, np.float64)
+    d = _c(d)
+    buf = np.ascontiguousarray(buf, np.float64).copy()
+    B, T = x.shape
+    y = np.empty_like(x)
+    rc = lib().ntmo_delay_forward_f64(_pd(x), _p(d), _pd(y), B, T, _pd(buf), buf.shape[1], int(bool(warmup)))
+    if rc == 1:
+        raise AssertionError("max_delay >= max(dt) violated")
+    assert rc == 0
+    return y, buf
+
+
+def diffdel_predict_f64(w, x, d, max_delay, threads=1):
+    """diffdel_predict in fp64 mode -> (y, pre_d, h_out, buf_out), all float64."""
+    x, d = _c(x), _c(d)
+    B = x.shape[0]
+    D = int(max_delay) + 1
+    z = np.zeros((1, 1024), np.float32)
+    p1, h1 = gru_forward_f64(w, z)
+    _, b1 = delay_forward_f64(p1, z, np.zeros((1, D)))
+    pre, h = gru_forward_f64(w, x, np.repeat(h1, B, 0), threads)
+    y, buf = delay_forward_f64(pre, d, np.repeat(b1, B, 0))
+    return y, pre, h, buf
 
 
 def esr_sums(y, t, skip=0):

@@ -110,6 +110,103 @@ int ntmo_gru_forward_mt(const float *w_ih, const float *w_hh, const float *b_ih,
 }
 
 /*
+ * fp64 mode of the same restatement (code/model.py:81-82 evaluated in double: fp32 parameters and input, `double` state,
+ * accumulators, exp / tanh): the yardstick that separates the device's rounding from the fp32 oracle's own -- per stream
+ * |hip - f64| against |oracle32 - f64| (tests/test_gpu_round6.py).  Not a parity target: the reference computes in fp32
+ * (model.py:76 casts to float); pinned to torch's double GRU by golden g6's fp64 twin (tests/test_oracle.py).
+ * y [B,T] and h_state [B,H] are double.
+ */
+static void gru_stream_f64(const float *w_ih, const double *wt, const float *b_ih, const float *b_hh,
+                           const float *w_o, const float *b_o, int H, const float *x, double *y, int64_t T, double *h)
+{
+    const int G = 3 * H;
+    double *gh = (double *)malloc(sizeof(double) * (size_t)G);
+    double *hn = (double *)malloc(sizeof(double) * (size_t)H);
+    for (int64_t t = 0; t < T; ++t) {
+        const double xt = (double)x[t];
+        for (int g = 0; g < G; ++g) gh[g] = 0.0;
+        for (int k = 0; k < H; ++k) {
+            const double hk = h[k];
+            const double *col = wt + (size_t)k * G;
+            for (int g = 0; g < G; ++g) gh[g] += col[g] * hk;
+        }
+        for (int g = 0; g < G; ++g) gh[g] += (double)b_hh[g];
+        double yo = 0.0;
+        for (int j = 0; j < H; ++j) {
+            const double gi_r = (double)w_ih[j] * xt + (double)b_ih[j];
+            const double gi_z = (double)w_ih[H + j] * xt + (double)b_ih[H + j];
+            const double gi_n = (double)w_ih[2 * H + j] * xt + (double)b_ih[2 * H + j];
+            const double r = 1.0 / (1.0 + exp(-(gi_r + gh[j])));
+            const double z = 1.0 / (1.0 + exp(-(gi_z + gh[H + j])));
+            const double n = tanh(gi_n + r * gh[2 * H + j]);
+            hn[j] = (h[j] - n) * z + n;
+            yo += (double)w_o[j] * hn[j];
+        }
+        memcpy(h, hn, sizeof(double) * (size_t)H);
+        y[t] = b_o ? yo + (double)b_o[0] : yo;
+    }
+    free(gh);
+    free(hn);
+}
+
+int ntmo_gru_forward_f64_mt(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                            const float *w_o, const float *b_o, int H, const float *x, double *y,
+                            int64_t B, int64_t T, double *h_state, int threads)
+{
+    if (H <= 0 || B < 0 || T < 0) return -1;
+    const int G = 3 * H;
+    double *wt = (double *)malloc(sizeof(double) * (size_t)G * (size_t)H);
+    for (int g = 0; g < G; ++g)
+        for (int k = 0; k < H; ++k) wt[(size_t)k * G + g] = (double)w_hh[(size_t)g * H + k];
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
+    for (int64_t b = 0; b < B; ++b)
+        gru_stream_f64(w_ih, wt, b_ih, b_hh, w_o, b_o, H, x + b * T, y + b * T, T, h_state + b * H);
+    free(wt);
+    return 0;
+}
+
+/* the delay line (code/model.py:269-320, closed form as below) on a double signal: the trajectory d stays the caller's fp32
+ * array (it is an INPUT), tap index and the two weights are evaluated in double.  Same return convention as ntmo_delay_forward. */
+int ntmo_delay_forward_f64(const double *x, const float *d, double *y, int64_t B, int64_t T, double *dl_state, int D, int warmup)
+{
+    if (D < 0 || B < 0 || T < 0) return -1;
+    for (int64_t i = 0; i < B * T; ++i)
+        if (d[i] > (float)D) return 1;
+    double *nb = (double *)malloc(sizeof(double) * (size_t)(D > 0 ? D : 1));
+    for (int64_t b = 0; b < B; ++b) {
+        const double *xb = x + b * T;
+        const float *db = d + b * T;
+        double *yb = y + b * T, *buf = dl_state + b * (int64_t)D;
+        if (warmup) {
+            if (yb != xb) memcpy(yb, xb, sizeof(double) * (size_t)T);
+        } else {
+            for (int64_t n = 0; n < T; ++n) {
+                const double dn = (double)db[n];
+                const int64_t k = (int64_t)floor(dn);
+                double acc = 0.0;
+                for (int64_t m = k + 1; m >= k; --m) {
+                    if (m < 0 || m > D) continue;
+                    const double w = 1.0 - fabs((double)m - dn);
+                    if (!(w > 0.0)) continue;
+                    const int64_t src = n - m;
+                    acc += w * (src >= 0 ? xb[src] : buf[D + src]);
+                }
+                yb[n] = acc;
+            }
+        }
+        if (T >= D) {
+            memcpy(nb, xb + (T - D), sizeof(double) * (size_t)D);
+        } else {
+            memcpy(nb, buf + T, sizeof(double) * (size_t)(D - T));
+            memcpy(nb + (D - T), xb, sizeof(double) * (size_t)T);
+        }
+        memcpy(buf, nb, sizeof(double) * (size_t)D);
+    }
+    free(nb);
+    return 0;
+}
+
+/*
  * code/model.py:269-320.  x,d,y [B,T]; dl_state [B,D] = the reference's `buffer` (oldest first).
  * Returns 0, or 1 if max(d) > D (the reference's `assert self.max_delay >= torch.max(dt)`, :284;
  * nothing is written in that case).  y may not alias x.

@@ -38,6 +38,14 @@ for B, T, D in ((1, 1, 1), (2, 5, 37), (3, 100, 37), (2, 37, 37), (1, 40, 8900))
 x = rng.uniform(-0.5, 0.5, (2, 700)).astype(np.float32)
 d = rng.uniform(0, 300, (2, 700)).astype(np.float32)
 oracle.diffdel_predict(wd, x, d, 300)
+oracle.diffdel_predict_f64(wd, x, d, 300)            # fp64 mode (round 6): GRU and delay line on double arrays
+oracle.gru_predict_f64(w, x[:, :33], threads=2)
+for T, D in ((1, 1), (5, 37), (37, 37)):
+    xd = rng.standard_normal((2, T))
+    dd = rng.uniform(0, D, (2, T)).astype(np.float32)
+    dd[0, 0], dd[-1, -1] = 0.0, D
+    oracle.delay_forward_f64(xd, dd, rng.standard_normal((2, D)))
+    oracle.delay_forward_f64(xd, dd, rng.standard_normal((2, D)), warmup=True)
 t = (x + 0.1 * rng.standard_normal(x.shape)).astype(np.float32)
 for skip in (0, 1, 699, 700):
     oracle.esr_sums(x, t, skip)

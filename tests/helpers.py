@@ -42,3 +42,22 @@ def validate_batches(seed, n_batches, b, t, fs):
         d = (100.0 + 45.0 * np.sin(2 * np.pi * f * n / fs * 40 + ph) + 5.0 * rng.uniform(-1, 1, (b, 1))) / fs
         out.append((x, tgt, d))
     return out
+
+
+def bench_record(stdout, detail=True):
+    """bench.py's output contract: exactly ONE JSON line on stdout, the last one, shorter than 4 KB (the driver's parser lost
+    round 5's 20 KB line), naming the detail file that holds the full record.  -> (compact line dict, full record dict);
+    the headline fields of the two agree."""
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and stdout.rstrip().splitlines()[-1] == lines[0], stdout[-2000:]
+    assert len(lines[0]) < 4096, len(lines[0])
+    c = json.loads(lines[0])
+    if not detail:
+        return c, None
+    path = c["detail_file"] if os.path.isabs(c["detail_file"]) else os.path.join(ROOT, c["detail_file"])
+    with open(path) as f:
+        d = json.load(f)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "scaling", "dtype", "data"):
+        assert c[k] == d[k], k
+    assert c["roofline"]["frac"] == d["roofline"]["frac"] and c["roofline"]["kernel_ms"] == d["roofline"]["kernel_ms"]
+    return c, d

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 import oracle
-from helpers import ROOT, load, oracle_weights
+from helpers import ROOT, bench_record, load, oracle_weights
 
 pytestmark = pytest.mark.gpu
 
@@ -327,9 +327,8 @@ def test_bench_spawns_its_own_ranks_on_one_gpu_over_gloo():
                             "--samples", "4096", "--no-cpu-baseline", "--no-extra"] + extra,
                            env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        assert len(lines) == 1, r.stdout
-        out = json.loads(lines[0])
+        line, out = bench_record(r.stdout)                  # one compact line (< 4 KB) + the detail file it names
+        assert line["n_gpus"] == 2 and line["backend"] == "gloo" and line["rccl_ranks"] == 0 and "roofline" in line
         assert out["n_gpus"] == 2 and out["ranks"] == 2 and out["backend"] == "gloo" and out["rccl_ranks"] == 0
         assert [d["rank"] for d in out["rank_devices"]] == [0, 1]
         assert out["config"]["segments_total"] == total and out["checks"]["segments"] == total
@@ -353,7 +352,10 @@ def test_bench_one_rank_process_group_runs_the_rccl_calls():
                         "--batch", "512", "--samples", "4096", "--no-cpu-baseline", "--no-extra"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    line, out = bench_record(r.stdout)
+    # the compact line of the nccl code path: the first 8-GPU run must not be the first time it prints one
+    assert line["backend"].startswith("rccl") and line["rccl_ranks"] == 1 and line["ranks"] == 1 and line["n_gpus"] == 1
+    assert line["roofline"]["frac"] > 0 and line["checks"]["deterministic"] is True and line["checks"]["segments"] == 512
     assert out["backend"].startswith("rccl") and out["rccl_ranks"] == 1 and out["ranks"] == 1
     assert out["rank_devices"][0]["rank"] == 0 and out["rank_devices"][0]["device"] == 0
     assert out["checks"]["segments"] == 512 and out["checks"]["job_esr"] > 0 and out["checks"]["last_output_equals_first_pass_bitwise"] is True

@@ -14,7 +14,7 @@ import pytest
 import torch
 
 import oracle
-from helpers import ROOT, load, oracle_weights, validate_batches
+from helpers import ROOT, bench_record, load, oracle_weights, validate_batches
 
 pytestmark = pytest.mark.gpu
 
@@ -341,9 +341,8 @@ def test_bench_eight_ranks_share_the_gpu_over_gloo():
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + extra, env=env, capture_output=True,
                            text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
-        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        assert len(lines) == 1, r.stdout
-        out = json.loads(lines[0])
+        line, out = bench_record(r.stdout)
+        assert line["n_gpus"] == 8 and line["roofline"]["aggregate"]["n_gpus"] == 8 and "legs" not in line
         assert out["n_gpus"] == 8 and out["ranks"] == 8 and out["backend"] == "gloo" and out["rccl_ranks"] == 0
         assert [d["rank"] for d in out["rank_devices"]] == list(range(8)) and all(d["device"] == 0 for d in out["rank_devices"])
         assert out["config"]["segments_total"] == total and out["checks"]["segments"] == total
@@ -367,12 +366,13 @@ def test_bench_line_carries_the_other_workloads():
     as `other_workloads` (here at small shapes, `--other on`): each with kernel, kernel_ms, roofline.frac, determinism
     and scattered streams against the oracle; the headline fields are those of a run without them."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "1040",
-                        "--samples", "4096", "--no-extra", "--other", "on", "--other-steps", "2", "--other-gru-batches", "2048,4112", "--other-tcn-batches", "2048",
+                        "--samples", "4096", "--no-extra", "--other", "on", "--other-steps", "2", "--other-gru-batches", "2048,4112", "--other-tcn-batches", "2048", "--other-diffdel-batches", "",
                         "--cli-segments", "0"],              # (other_workloads.cli: tests/test_gpu_round5.py)
                        env=_clean_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    line, out = bench_record(r.stdout)
     ow = out["other_workloads"]
+    assert set(line["legs"]) == set(ow) - {"note"} and all(0 < v["frac"] < 1 and v["value"] > 0 for v in line["legs"].values())
     assert set(ow) == {"note", "diffdel", "tcn", "gru_B2048", "gru_B4112", "tcn_B2048"} and "not a scaling curve" in ow["note"]
     for k, v in ow.items():
         if k == "note":

@@ -27,7 +27,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import ROOT, load
+from helpers import ROOT, bench_record, load
 
 pytestmark = pytest.mark.gpu
 
@@ -338,9 +338,7 @@ def _bench(args, **env_extra):
     env.update(env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout
-    return json.loads(lines[0])
+    return bench_record(r.stdout)[1]            # (the compact line's length and agreement with the record are checked there)
 
 
 @FULL

@@ -8,7 +8,7 @@ import pytest
 import torch
 
 import oracle
-from helpers import ROOT, load
+from helpers import ROOT, bench_record, load
 
 pytestmark = pytest.mark.gpu
 
@@ -419,9 +419,10 @@ def test_bench_under_torch_distributed_run_two_ranks():
                         "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                         "--batch", "1040", "--cpu-sample", "small", "--no-extra"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    line, d = bench_record(r.stdout)            # the N-rank compact line: < 4 KB, parseable, roofline + cpu_baseline on it
+    assert line["n_gpus"] == 2 and line["cpu_baseline"]["value"] > 0 and line["roofline"]["aggregate"]["n_gpus"] == 2
+    assert line["roofline"]["traffic_live"] is True and 1.0 <= line["roofline"]["traffic_ratio"] < 1.02
+    assert line["checks"]["streams_vs_oracle_max_abs"] < TOL and line["checks"]["esr_sums_max_rel"] < 1e-9
     assert d["n_gpus"] == 2 and d["ranks"] == 2 and d["backend"] == "gloo" and d["config"]["segments_total"] == 2080
     assert d["metric"] == "audio samples/sec (44.1 kHz) GRU-HS[64], batch=1040x65536 per GPU, 2 GPU (weak scaling, 2080 segments)"
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == min(32, len(os.sched_getaffinity(0)))
@@ -439,10 +440,24 @@ W_D = "DiffDelGRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE
 
 def _record_full(name, **row):
     import json
-    path = os.path.join(ROOT, "gpurun_out", "r05_full_batch_parity.jsonl")
+    path = os.path.join(ROOT, "gpurun_out", "r06_full_batch_parity.jsonl")
     os.makedirs(os.path.dirname(path), exist_ok=True)
+    lib = os.path.basename(os.environ.get("NTM_LIB_PATH") or "libntm.so")       # (libntm_tanh1.so: the tanh-form A/B of round 6)
     with open(path, "a") as f:
-        f.write(json.dumps(dict(config=name, **row)) + "\n")
+        f.write(json.dumps(dict(config=name, library=lib, **row)) + "\n")
+
+
+def _margin(hip, or32, f64):
+    """Per stream: |hip - f64|, |oracle32 - f64| (the fp32 restatement's OWN rounding error on that stream) and their ratio --
+    how much of the 1e-5 bar the device's arithmetic uses, separated from what any fp32 evaluation of the recurrence uses.
+    -> dict of the distribution over the streams (worst / p99 / median each, the worst stream's numbers, the ratio's)."""
+    dh = np.abs(hip - f64).max(axis=1)
+    do = np.abs(or32 - f64).max(axis=1)
+    ratio = dh / np.maximum(do, 1e-12)
+    q = lambda v: {"worst": float(v.max()), "p99": float(np.quantile(v, 0.99)), "median": float(np.median(v))}      # noqa: E731
+    i = int(dh.argmax())
+    return {"hip_vs_f64": q(dh), "oracle32_vs_f64": q(do), "ratio_per_stream": q(ratio), "ratio_of_worsts": float(dh.max() / do.max()),
+            "worst_stream": {"stream": i, "hip_vs_f64": float(dh[i]), "oracle32_vs_f64": float(do[i])}}
 
 
 @FULL
@@ -450,7 +465,9 @@ def test_full_size_cfg2_every_stream_against_the_oracle(ntm):
     """BASELINE configs[1] at full size, ALL 4096 streams x 65 536 samples against the C oracle (rounds 2-4 checked 36
     scattered streams: the torch-CPU reference takes half an hour for the batch, the OpenMP oracle -- itself pinned to the
     reference by goldens g1 / g2 / g6 / g19 / g20 -- about 20 s on the box's cores).  Output and carried state of every
-    stream inside 1e-5; the distribution of the per-stream maximum goes into gpurun_out/r05_full_batch_parity.jsonl."""
+    stream inside 1e-5.  Round 6: the oracle's fp64 mode (pinned to torch's double modules by g20) separates the device's
+    rounding from the fp32 oracle's own: per stream |hip - f64| and |oracle32 - f64|; the distributions go into
+    gpurun_out/r06_full_batch_parity.jsonl (run again with NTM_LIB_PATH=.../libntm_tanh1.so for the tanh-form A/B)."""
     import sys
     import time
     from helpers import oracle_weights
@@ -467,16 +484,24 @@ def test_full_size_cfg2_every_stream_against_the_oracle(ntm):
     t0 = time.perf_counter()
     yo, ho = oracle.gru_predict(oracle_weights(W_G), xs, threads=threads)
     dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    y64, h64 = oracle.gru_predict_f64(oracle_weights(W_G), xs, threads=threads)
+    dt64 = time.perf_counter() - t0
     per = np.abs(y - yo).max(axis=1)
+    mg = _margin(y, yo, y64)
     _record_full("configs[1] GRU-HS[64] 4096 x 65536", streams=B, worst=float(per.max()), worst_stream=int(per.argmax()), median=float(np.median(per)),
-                 p99=float(np.quantile(per, 0.99)), state_worst=float(np.abs(h - ho).max()), oracle_seconds=dt, oracle_threads=threads)
+                 p99=float(np.quantile(per, 0.99)), state_worst=float(np.abs(h - ho).max()), margin_y=mg,
+                 state_hip_vs_f64=float(np.abs(h - h64).max()), state_oracle32_vs_f64=float(np.abs(ho - h64).max()),
+                 oracle_seconds=dt, oracle_f64_seconds=dt64, oracle_threads=threads)
     assert per.max() < TOL and np.abs(h - ho).max() < TOL, (per.max(), int(per.argmax()))
+    assert mg["hip_vs_f64"]["worst"] < TOL and mg["oracle32_vs_f64"]["worst"] < TOL      # each within the bar of the truth itself
 
 
 @FULL
 def test_full_size_cfg3_every_stream_against_the_oracle(ntm):
     """BASELINE configs[2] at full size: DiffDelGRU (fused step), all 4096 (signal, wow trajectory) pairs x 65 536, D = 1847:
-    pre_d and y of every stream inside 1e-5 of the oracle, hidden state and delay buffer too."""
+    pre_d and y of every stream inside 1e-5 of the oracle, hidden state and delay buffer too; the fp64-mode margins of pre_d and
+    y as in the configs[1] test."""
     import sys
     import time
     from helpers import oracle_weights
@@ -497,10 +522,18 @@ def test_full_size_cfg3_every_stream_against_the_oracle(ntm):
     yo, preo, ho, bo = oracle.diffdel_predict(oracle_weights(W_D), xs, ds, m.max_delay, threads=threads)
     dt = time.perf_counter() - t0
     per_y, per_p = np.abs(y - yo).max(axis=1), np.abs(pre - preo).max(axis=1)
+    t0 = time.perf_counter()
+    y64, p64, _, _ = oracle.diffdel_predict_f64(oracle_weights(W_D), xs, ds, m.max_delay, threads=threads)
+    dt64 = time.perf_counter() - t0
+    mp = _margin(pre, preo, p64)
+    del p64, preo
+    my = _margin(y, yo, y64)
     _record_full("configs[2] DiffDelGRU-HS[64] 4096 x 65536, D = 1847 (fused step)", streams=B, worst_y=float(per_y.max()), worst_pre_d=float(per_p.max()),
                  worst_stream=int(per_p.argmax()), median_pre_d=float(np.median(per_p)), p99_pre_d=float(np.quantile(per_p, 0.99)),
-                 state_worst=float(np.abs(h - ho).max()), buffer_worst=float(np.abs(buf - bo).max()), oracle_seconds=dt, oracle_threads=threads)
+                 state_worst=float(np.abs(h - ho).max()), buffer_worst=float(np.abs(buf - bo).max()), margin_pre_d=mp, margin_y=my,
+                 oracle_seconds=dt, oracle_f64_seconds=dt64, oracle_threads=threads)
     assert per_y.max() < TOL and per_p.max() < TOL and np.abs(h - ho).max() < TOL and np.abs(buf - bo).max() < TOL
+    assert mp["hip_vs_f64"]["worst"] < TOL and my["hip_vs_f64"]["worst"] < TOL
 
 
 # ----------------------------------------------------------------------------- DiffDelGRU: both time-domain losses out of the fused step

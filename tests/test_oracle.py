@@ -428,3 +428,24 @@ def test_oracle_at_the_harness_operating_point_g20():
         assert np.abs(y[0] - g[f"dd_{tag}_y"]).max() < 1e-5 and np.abs(pre[0] - g[f"dd_{tag}_pre"]).max() < 1e-5
         assert np.abs(buf[0] - g[f"dd_{tag}_buffer"]).max() < 1e-5
         assert g[f"dd_{tag}_gate_noise"].max() < 1e-5
+
+
+def test_oracle_fp64_mode_against_the_reference_modules_in_double_g20():
+    """The oracle's fp64 mode (ntmo_gru_forward_f64_mt / ntmo_delay_forward_f64: fp32 parameters and input, double state,
+    accumulators and gates) against golden g20's `*_y64` -- torch.nn.GRU / nn.Linear, the modules code/model.py:44-45 builds,
+    cast to double by tools/make_goldens_checkpoints.py f64_truth and stored as float32: they agree to the rounding of that
+    final cast (half an ulp of |y| < 0.5, i.e. 3e-8), three hundred times closer than either is to any fp32 evaluation.
+    It is the yardstick of tests/test_gpu_round6.py (|hip - f64| against |oracle32 - f64| per stream), not a parity target."""
+    g = load("g20_operating_point.npz")
+    x = (g["gru_x_int16"].astype(np.float32) / 32768.0)[None]
+    for tag in ("chow", "akai"):
+        w = oracle_weights(str(g[f"gru_{tag}_weights"]))
+        y64, h64 = oracle.gru_predict_f64(w, x, threads=2)
+        assert y64.dtype == np.float64 and np.abs(y64[0] - g[f"gru_{tag}_y64"].astype(np.float64)).max() < 4e-8, tag
+        y32, _ = oracle.gru_predict(w, x)
+        e32 = np.abs(y32[0].astype(np.float64) - y64[0]).max()
+        assert 1e-7 < e32 and abs(e32 - np.abs(y32[0] - g[f"gru_{tag}_y64"]).max()) < 1e-7       # fp32 is measurably off, fp64 mode is not
+    x = (g["dd_toy_x_int16"].astype(np.float32) / 32768.0)[None]
+    y, pre, h, buf = oracle.diffdel_predict_f64(oracle_weights(str(g["dd_toy_weights"])), x, g["dd_toy_d"][None], int(g["dd_toy_max_delay"]))
+    assert np.abs(pre[0] - g["dd_toy_pre64"].astype(np.float64)).max() < 4e-8 and np.abs(y[0] - g["dd_toy_y64"].astype(np.float64)).max() < 4e-8
+    assert np.abs(buf[0] - g["dd_toy_buffer"]).max() < 1e-5 and np.abs(h[0] - g["dd_toy_hidden"]).max() < 1e-5
