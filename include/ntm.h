@@ -325,7 +325,10 @@ int ntm_fir_f64(const double *x, double *y, int64_t B, int64_t N, const double *
  * activation buffers inside `scratch` and its own HIP stream, forked from and joined to `stream` by events (the two side
  * streams and three events are created on the first chunked call on a device and kept -- the library's only state, it
  * holds no data): the call returns as soon as the work is enqueued, is ordered on `stream` like any other, and one
- * chunk's drain and HBM-bound first block run under the other chunk's matrix-pipe blocks.  Limits: T < 2^31 - 2^25,
+ * chunk's drain and HBM-bound first block run under the other chunk's matrix-pipe blocks.  A call made while `stream` is
+ * being CAPTURED into a graph does not touch the shared lanes: its chunks are enqueued one after the other on `stream`
+ * itself (same results; the lanes belong to every caller on the device, and a lane forked into one capture would pull
+ * another thread's concurrent call into it).  Limits: T < 2^31 - 2^25,
  * 1 <= dil[l] <= 2^20 (NTM_EINVAL otherwise).
  */
 int ntm_tcn_forward(const float *params, int L, int C, int K, const int *dil, const float *x,

@@ -556,6 +556,21 @@ int ntm_tcn_forward(const float *params, int L, int C, int K, const int *dil, co
     // captured into a graph).  The pool's mutex is held while the call ENQUEUES (microseconds): calls on one device share
     // the lanes, which only serialises work that would contend for the same CUs anyway.
     const int64_t lane_floats = 2 * (bc * T * (int64_t)C + 16 * (int64_t)C);
+    // A call under stream capture keeps to the caller's stream: the pooled lanes are shared by every caller on the device, and
+    // a lane forked into one caller's capture would drag a concurrent, un-captured call of another thread into that capture
+    // (or fail it with a capture-isolation error); stream and event creation cannot be captured either.  The chunks then run
+    // one after the other on `stream`, still alternating the two scratch halves -- same results, no lane overlap in the graph.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(user, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+    if (cap != hipStreamCaptureStatusNone) {
+        hipError_t ec = hipSuccess;
+        int kc = 0;
+        for (int64_t b0 = 0; b0 < B && ec == hipSuccess; b0 += bc, ++kc) {
+            const int64_t n = B - b0 < bc ? B - b0 : bc;
+            ec = ntm::launch_tcn(params, L, C, K, dil, x + b0 * T, y + b0 * T, n, T, scratch + (kc & 1) * lane_floats, user);
+        }
+        return ec == hipSuccess ? NTM_OK : hip_fail(ec, "ntm_tcn_forward");
+    }
     int devi = 0;
     hipError_t e = hipGetDevice(&devi);
     if (e != hipSuccess) return hip_fail(e, "ntm_tcn_forward");
@@ -563,12 +578,25 @@ int ntm_tcn_forward(const float *params, int L, int C, int K, const int *dil, co
     TcnLanes &P = g_tcn_lanes[devi];
     std::lock_guard<std::mutex> hold(P.mu);
     if (!P.ready) {
-        e = hipEventCreateWithFlags(&P.fork, hipEventDisableTiming);
+        // built into locals and committed only when all five handles exist: a failure half way destroys what it made
+        // (a retry used to overwrite, i.e. leak, the handles of the first attempt)
+        hipEvent_t fork = nullptr, done[2] = {nullptr, nullptr};
+        hipStream_t lane[2] = {nullptr, nullptr};
+        e = hipEventCreateWithFlags(&fork, hipEventDisableTiming);
         for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-            e = hipStreamCreateWithFlags(&P.lane[i], hipStreamNonBlocking);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&P.done[i], hipEventDisableTiming);
+            e = hipStreamCreateWithFlags(&lane[i], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
         }
-        if (e != hipSuccess) return hip_fail(e, "ntm_tcn_forward");       // (a half-built pool is retried by the next call)
+        if (e != hipSuccess) {
+            if (fork) (void)hipEventDestroy(fork);
+            for (int i = 0; i < 2; ++i) {
+                if (done[i]) (void)hipEventDestroy(done[i]);
+                if (lane[i]) (void)hipStreamDestroy(lane[i]);
+            }
+            return hip_fail(e, "ntm_tcn_forward");
+        }
+        P.fork = fork;
+        for (int i = 0; i < 2; ++i) { P.lane[i] = lane[i]; P.done[i] = done[i]; }
         P.ready = true;
     }
     e = hipEventRecord(P.fork, user);

@@ -255,6 +255,18 @@ def demodulate(output, x_idx_pulse, y_idx_pulse):
     return out
 
 
+def decoded_bytes(path, with_trajectory=False):
+    """Bytes `path` occupies once decoded to float32 [C, N] (+ a float32 trajectory of N samples), from its WAV header (the
+    file is memory-mapped, nothing is read); a format scipy cannot map (24-bit PCM) is bounded by 4 bytes per byte on disk."""
+    try:
+        _, a = wavfile.read(path, mmap=True)
+        frames, ch = (a.shape[0], 1) if a.ndim == 1 else a.shape
+        del a
+    except (ValueError, OSError):
+        frames, ch = os.path.getsize(path), 4
+    return 4 * frames * ch + (4 * frames if with_trajectory else 0)
+
+
 class SegmentFeeder:
     def __init__(self, data_dir, subset="train", length=44100, input_only=False, sync=0.0, demodulate=False,
                  analyze=True, write_sidecars=True, fraction=1.0, shuffle=False, seed=None, resident=None):
@@ -277,15 +289,34 @@ class SegmentFeeder:
         self.examples = []
         self._audio = []
         # `resident`: the decoded set lives ON THE DEVICE (read_wav_device: the decode is the H2D copy; batches are then
-        # device-to-device gathers and predict_streamed one launch).  None = yes when a HIP device is present and the files
-        # (fp32 audio + fp32 trajectories, ~1.5 x their size on disk at worst) fit half of its free memory; False = the
-        # pinned-host layout with H2D copies per batch (what a set larger than the device needs).
-        if resident is None:
+        # device-to-device gathers and predict_streamed one launch).  None = yes when a HIP device is present and the DECODED
+        # set -- frames x channels x 4 bytes per file from the WAV headers, + frames x 4 for a trajectory side-car: int16 PCM
+        # decodes to 2 x its file size, uint8 to 4 x -- fits half of the device's free memory; False = the pinned-host layout
+        # with H2D copies per batch (what a set larger than the device needs).  An automatic choice that still runs out of
+        # device memory (another process took it meanwhile) frees what it uploaded and falls back to the pinned-host layout.
+        auto = resident is None
+        if auto:
             resident = False
             if torch.cuda.is_available():
-                need = 2 * sum(os.path.getsize(f) for f in self.input_files + [t for t in self.target_files if t])
+                need = sum(decoded_bytes(f, with_trajectory=os.path.exists(sidecar_path(f))) for f in self.input_files)
+                need += sum(decoded_bytes(t) for t in self.target_files if t)
                 resident = need < 0.5 * torch.cuda.mem_get_info()[0]
         self.resident = bool(resident)
+        try:
+            self._decode_all(input_only, analyze, write_sidecars)
+        except torch.cuda.OutOfMemoryError:
+            if not (auto and self.resident):
+                raise
+            self.examples, self._audio, self.fs = [], [], None
+            self.mean_delay, self.max_delay, self.min_delay = 0.0, 0.0, 1e6
+            _stage.clear()
+            torch.cuda.empty_cache()
+            self.resident = False
+            self._decode_all(input_only, analyze, write_sidecars)
+        self._finish(demodulate, fraction, shuffle, seed)
+
+    def _decode_all(self, input_only, analyze, write_sidecars):
+        """Decode every file pair (+ side-car) into the layout self.resident names; fills _audio, examples, the delay statistics."""
         for idx, (ifile, tfile) in enumerate(zip(self.input_files, self.target_files)):
             if not input_only and _file_id(ifile) != _file_id(tfile):
                 raise RuntimeError(f"Found non-matching file ids: {_file_id(ifile)} != {_file_id(tfile)}! Check dataset.")
@@ -355,6 +386,8 @@ class SegmentFeeder:
             start = int(self.sync * self.fs)
             for n_chunk in range((num_frames - start) // self.length):
                 self.examples.append({"idx": idx, "offset": n_chunk * self.length + start})
+
+    def _finish(self, demodulate, fraction, shuffle, seed):
         n_traj = sum(1 for a in self._audio if a[2] is not None)
         self.mean_delay = self.mean_delay / n_traj if n_traj else 0.0               # utilities.py:341
         assert not (demodulate and n_traj != len(self._audio)), "Can't demodulate without trajectory side-cars!"

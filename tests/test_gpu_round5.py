@@ -1,6 +1,7 @@
 """Round 5: ANY hidden size (the reference's `--HIDDEN_SIZE` is a free integer, code/train.py:50, code/model.py:22,44-45) against
 goldens made by the reference itself (g21, tools/make_goldens_anyh.py) and the oracle; the evaluation CLI's loss cache
 (tools/test_model.py) with directory-path weights and changed arguments; the DCPreESR sums out of the recurrent launch."""
+import ctypes
 import os
 
 import numpy as np
@@ -165,6 +166,14 @@ def test_cli_loss_cache_with_directory_weights_and_changed_arguments(tmp_path, m
     assert "Starting analysis" in out and "Stats:" in out and "cache not written" not in out
     cache = list((tmp_path / "tmp" / "loss" / "Wow" / "Test").glob("*.npy"))
     assert len(cache) == 1 and name in cache[0].name and os.sep not in cache[0].name
+    # the .npy holds exactly what upstream's does -- a plain {loss: float} dict its stats loop can format
+    # (code/test-model.py:399-403,414-415) -- and the argument record sits in a side-car; an upstream-written cache (no
+    # side-car) is recomputed, not trusted
+    import json
+    blob = np.load(str(cache[0]), allow_pickle=True).item()
+    assert set(blob) == set(got) and all(isinstance(v, float) and "{:.6f}".format(v) for v in blob.values())
+    rec = json.load(open(str(cache[0])[:-4] + ".key.json"))
+    assert rec["segments"] == N // 12000 and rec["key"]["segment_length"] == 12000 and rec["key"]["kernel"] == "auto"
     # the numbers: the oracle on the same segments with the same checkpoint
     T = g["T1"]
     init = 1 << (int(T.max() * fs) - 1).bit_length()
@@ -179,6 +188,8 @@ def test_cli_loss_cache_with_directory_weights_and_changed_arguments(tmp_path, m
     out = capsys.readouterr().out
     assert "recomputing" in out and "Starting analysis" in out and other["ESR"] != got["ESR"]
     assert cli.main(argv) != other and "recomputing" in capsys.readouterr().out           # ... and back: the file holds the 9000 run now
+    os.remove(str(cache[0])[:-4] + ".key.json")                  # what an upstream-written cache looks like
+    assert cli.main(argv) == got and "no argument record" in capsys.readouterr().out
     stamp = cache[0].stat().st_mtime_ns
     assert cli.main(argv + ["--NO_CACHE"]) == got
     out = capsys.readouterr().out
@@ -213,13 +224,27 @@ def test_chunked_tcn_call_returns_before_its_work_and_can_be_captured(ntm):
         devms.append(e0.elapsed_time(e1))
         assert torch.equal(y, y0)
     assert min(host) < 0.5 * min(devms), (host, devms)
-    # the same call under stream capture (torch allocates y from the graph's private pool)
+    # the same call under stream capture (torch allocates y from the graph's private pool): a captured call keeps to the
+    # caller's stream (the pooled lanes are shared, a lane forked into one capture would pull a concurrent
+    # call of another thread into it), so an un-captured call on another stream WHILE the capture is open must go through
     s = torch.cuda.Stream()
+    other = torch.cuda.Stream()
+    L_ = ntm._lib
+    y_other = torch.empty_like(x)                           # everything the un-captured call needs exists before the capture opens
+    scratch = torch.empty(int(L.ntm_tcn_scratch_floats(B, T, 32)), device="cuda")
+    packed = tcn.packed_params()
+    dil = (ctypes.c_int * len(tcn.dilations))(*tcn.dilations)
+    torch.cuda.synchronize()
     s.wait_stream(torch.cuda.current_stream())
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.stream(s):
-        with torch.cuda.graph(graph, stream=s):
+        with torch.cuda.graph(graph, stream=s, capture_error_mode="relaxed"):
             yg = tcn(x)
+            rc = L.ntm_tcn_forward(L_.ptr(packed), len(tcn.dilations), 32, 13, dil, L_.ptr(x), L_.ptr(y_other), B, T,
+                                   L_.ptr(scratch), ctypes.c_void_p(other.cuda_stream))       # not part of the capture: on the lanes, now
+            assert rc == 0, L.ntm_last_error()
+    other.synchronize()
+    assert torch.equal(y_other, y0)
     torch.cuda.current_stream().wait_stream(s)
     yg.zero_()
     graph.replay()

@@ -19,7 +19,9 @@
 #include <vector>
 
 #include "ntm.h"
+#ifndef NTM_NO_RCCL          // (tools/cabi/Makefile: a box without the RCCL development files builds the demo without `reduce`)
 #include "ntm_rccl.h"
+#endif
 
 static std::vector<float> read_f32(const char *path, size_t want)
 {
@@ -132,6 +134,9 @@ static int diffdel_main(int argc, char **argv)
     return 0;
 }
 
+#ifdef NTM_NO_RCCL
+static int reduce_main(int, char **) { fprintf(stderr, "built without RCCL (rccl/rccl.h absent at build time): no `reduce`\n"); return 16; }
+#else
 static int reduce_main(int argc, char **argv)
 {
     if (argc != 8) { fprintf(stderr, "usage: %s reduce w0.bin x.f32 target.f32 B T skip\n", argv[0]); return 1; }
@@ -171,6 +176,7 @@ static int reduce_main(int argc, char **argv)
     printf("ok reduce ranks=1 sum_esr=%.17g segments=%.17g sum_err2=%.17g sum_tgt2=%.17g job_esr=%.17g\n", h4[0], h4[1], h4[2], h4[3], h4[0] / h4[1]);
     return 0;
 }
+#endif
 
 int main(int argc, char **argv)
 {

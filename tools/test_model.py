@@ -27,6 +27,7 @@ the dataset's measured maximum.  Extra flags of this build: --DATASET_DIR --AUDI
 --TEMP_PATH --NO_CACHE --BATCH_SIZE --STREAM_CHUNK --MAX_DELAY --INIT_LEN --KERNEL --SEED --NO_EXAMPLE.
 """
 import argparse
+import json
 import os
 import time
 import sys
@@ -173,8 +174,11 @@ class StageTimes:
         torch.cuda.synchronize()
         out = {k + "_ms": sum(a.elapsed_time(b) for a, b in v) for k, v in self.events.items()}
         if self.h2d:
-            out["h2d_ms"] = sum(a.elapsed_time(b) for a, b, _ in self.h2d)
-            out["h2d_bytes"] = sum(n for _, _, n in self.h2d)
+            # what the feeder's per-batch copies were: host-to-device DMA from the pinned set, or -- a device-resident set --
+            # device-to-device gathers (`batch_copy_kind`; the h2d_* names are kept for older readers of the profile)
+            out["h2d_ms"] = out["batch_copy_ms"] = sum(a.elapsed_time(b) for a, b, _ in self.h2d)
+            out["h2d_bytes"] = out["batch_copy_bytes"] = sum(n for _, _, n in self.h2d)
+            out["batch_copy_kind"] = "device_to_device_gather" if self.host.get("resident") else "host_to_device"
         out.update(self.host)
         return out
 
@@ -267,20 +271,29 @@ def compute_loss(a, feeder, model, names, delay, is_dd, init_len, rank, world, s
     cached = os.path.join(save_path, save_name)
     cache_key = loss_cache_key(a, feeder, names, init_len)
     results = None
+    keyfile = cached[:-4] + ".key.json"
     if os.path.exists(cached) and not a.NO_CACHE:
-        # every rank takes the same decision: it depends on the file and the arguments only
-        why = "unreadable"
+        # every rank takes the same decision: it depends on the files and the arguments only.  The .npy holds what upstream's
+        # holds -- a plain {loss name: float} dict (code/test-model.py:399-403; its stats loop formats every value with
+        # '{:.6f}') -- so either program can load the other's cache; the argument record lives in a side-car beside it
+        # (<name>.key.json).  A cache without a side-car (upstream's own) carries no record of its arguments: recomputed.
+        why, blob, rec = "unreadable", None, None
         try:
             blob = np.load(cached, allow_pickle=True).item()
         except Exception as e:
-            blob, why = None, f"unreadable: {type(e).__name__}"
-        if isinstance(blob, dict) and blob.get("_key") == cache_key:
+            why = f"unreadable: {type(e).__name__}"
+        try:
+            with open(keyfile) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            rec = None
+        if isinstance(blob, dict) and isinstance(rec, dict) and rec.get("key") == json.loads(json.dumps(cache_key)):
             say(" Loading pre-computed!")
-            results = {k: v for k, v in blob.items() if not k.startswith("_")}
-            n_seg = blob.get("_segments", len(feeder))
+            results = {k: float(v) for k, v in blob.items() if not k.startswith("_")}
+            n_seg = rec.get("segments", len(feeder))
         else:
             if isinstance(blob, dict):
-                old = blob.get("_key")
+                old = rec.get("key") if isinstance(rec, dict) else None
                 why = ("differs in " + ", ".join(sorted(k for k in set(old) | set(cache_key) if old.get(k) != cache_key.get(k)))
                        if isinstance(old, dict) else "no argument record")
             say(f" (cached results belong to other arguments [{why}]: recomputing)", end="")
@@ -363,7 +376,9 @@ def compute_loss(a, feeder, model, names, delay, is_dd, init_len, rank, world, s
         if rank == 0 and not a.NO_CACHE:
             try:                                   # a cache that cannot be written must never cost the printed results
                 os.makedirs(save_path, exist_ok=True)
-                np.save(cached, dict(results, _key=cache_key, _segments=n_seg))
+                np.save(cached, {k: float(v) for k, v in results.items()})          # upstream's format exactly
+                with open(keyfile, "w") as f:
+                    json.dump({"key": cache_key, "segments": int(n_seg)}, f, indent=1)
             except OSError as e:
                 say(f"(loss cache not written: {e})")
     say()
