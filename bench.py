@@ -134,7 +134,7 @@ _LIVE_CACHE = {}
 
 def profile_traffic(pattern, key):
     """(value, source note) from the newest tracked profiles/<pattern> (rocprofv3 --pmc passes of that leg's own command,
-    tools/gpu_r04_pmc.sh; not re-measured in this run), or (None, None)."""
+    tools/attic/gpu_r04_pmc.sh; not re-measured in this run), or (None, None)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
     if not files:
@@ -515,6 +515,11 @@ def compact_line(out, detail_file):
     if "vs_oracle_max_abs" in k:                  # a --workload line: measure_workload's own checks
         ck = {"deterministic": k.get("deterministic"), "streams_vs_oracle_max_abs": _sig(k.get("vs_oracle_max_abs"), 3), "tolerance": 1e-5}
     c["checks"] = {n: v for n, v in ck.items() if v is not None}
+    ok = out.get("other_kernels") or {}
+    eng = {n: {"kernel_ms": _sig(ok[n]["kernel_ms"], 5), "vs_exact_fp32_max_abs": _sig(ok[n]["max_abs_diff_vs_exact_fp32_whole_batch"], 3)}
+           for n in ("f16x3", "bf16x3") if n in ok}
+    if eng:                                       # the opt-in split engines: beside `value`, never in it
+        c["opt_in_engines"] = eng
     ow = out.get("other_workloads")
     if ow:
         c["legs"] = {n: _leg(v) for n, v in ow.items() if n != "note"}
@@ -530,7 +535,7 @@ def compact_line(out, detail_file):
     c["detail_file"] = detail_file
     line = json.dumps(c, separators=(",", ":"))
     if len(line) >= COMPACT_LIMIT:                # never again a line the driver cannot parse: shed the optional parts, in this order
-        for drop in ("legs", "build", "checks"):
+        for drop in ("opt_in_engines", "legs", "build", "checks"):
             c.pop(drop, None)
             line = json.dumps(c, separators=(",", ":"))
             if len(line) < COMPACT_LIMIT:
@@ -810,7 +815,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch segments per GPU (N = 8: BASELINE configs[4]); strong: --total-batch segments over all GPUs")
     ap.add_argument("--total-batch", type=int, default=32768, help="segments of the whole job under --scaling strong")
-    ap.add_argument("--variant", default="auto", choices=["auto", "mfma2", "mfma4", "mfma", "valu", "f16x3"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "mfma2", "mfma4", "mfma", "valu", "f16x3", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="full", choices=["full", "small"],
                     help="cpu_baseline: full = 16 x 8192 best of 3 + 64 x 8192 (about 10 s); small = 16 x 8192 once (tests)")
@@ -1035,6 +1040,37 @@ def main():
         if gold is not None:
             extra["f16x3"]["stream0_vs_reference_max_abs"] = float(
                 np.abs(gold["y"][0, 0] - y2[0, 0].cpu().numpy()).max())
+        # the bf16x3 engine (round 6, opt-in): W and h as three bf16 pieces each -- the fp32 operands exactly -- and W.h as eight
+        # of their nine partial products on the bf16 matrix pipe, fp32 accumulate; executed-MFMA flops against the bf16 peak AND
+        # the algorithmic 25 088 flop/sample against the fp32 peak, whole batch against the exact-fp32 pass
+        model.kernel_variant = "bf16x3"
+        ms3 = []
+        for i in range(2 + 5):
+            y4, _ = one_pass(None)
+            torch.cuda.synchronize()
+            if i >= 2:
+                ms3.append(ev0.elapsed_time(ev1))
+        k3 = float(np.mean(ms3)) / 1e3
+        s4 = esr_sums(y4, y_first, skip=INIT_LEN).sum(dim=0)
+        mfma_flop = 8 * 2 * 12288                        # eight products of the 192 x 64 GEMV, 2 flop per multiply-add
+        extra["bf16x3"] = {
+            "what": "same kernel with W and h as three bf16 pieces each (24 bits: the fp32 operands exactly), W.h = 8 of the 9 partial "
+                    "products (W_3.h_3 <= 2^-32 |W||h| dropped) on v_mfma_f32_16x16x32_bf16, fp32 accumulate; hand-scheduled step (opt-in)",
+            "kernel_ms": 1e3 * k3, "samples_per_s_kernel": B * T / k3, "speedup_vs_exact_fp32_kernel": kern_ms_rank / (1e3 * k3),
+            "cycles_per_step_at_2p4_GHz": k3 / T * 2.4e9,
+            "roofline_executed": {"bound": "mfma", "achieved": mfma_flop * B * T / k3 / 1e12, "peak": 2500.0, "unit": "TFLOP/s",
+                                  "frac": mfma_flop * B * T / k3 / 1e12 / 2500.0, "flop_per_sample": mfma_flop,
+                                  "what": "executed bf16 MFMA flops against the dense bf16 peak"},
+            "roofline_algorithmic": {"bound": "mfma", "achieved": FLOP_PER_SAMPLE * B * T / k3 / 1e12, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": FLOP_PER_SAMPLE * B * T / k3 / 1e12 / PEAK_FP32_TFLOPS, "flop_per_sample": FLOP_PER_SAMPLE,
+                                     "what": "the algorithmic flops of the fp32 recurrence against the fp32 peak (may exceed 1: "
+                                             "the engine does not run on the fp32 pipe)"},
+            "max_abs_diff_vs_exact_fp32_whole_batch": (y4 - y_first).abs().max().item(),
+            "esr_vs_exact_fp32_whole_batch": float(s4[0] / (s4[1] + ESR_EPS * B * (T - INIT_LEN))),
+            "parity_table": "profiles/r06_*_full_batch_parity.jsonl, profiles/r06_*_checkpoint_parity.jsonl (|hip - f64| beside the exact engine's)"}
+        if gold is not None:
+            extra["bf16x3"]["stream0_vs_reference_max_abs"] = float(np.abs(gold["y"][0, 0] - y4[0, 0].cpu().numpy()).max())
+        del y4
         model.kernel_variant = a.variant
         # the loss dict that follows the path in code/test-model.py:250-254 (never part of `value` beyond the ESR
         # sums the timed step already contains): ESR, DCPreESR and MultiSTFT over the whole batch, f16x3 output
@@ -1089,6 +1125,8 @@ def main():
     flop_per_sample, peak_tflops, dtype = FLOP_PER_SAMPLE, PEAK_FP32_TFLOPS, "f32"
     if a.variant == "f16x3":
         flop_per_sample, peak_tflops, dtype = 3 * 2 * 12288 + 2 * (192 + 64), 2500.0, "f16x3 products, f32 accumulate"
+    if a.variant == "bf16x3":
+        flop_per_sample, peak_tflops, dtype = 8 * 2 * 12288 + 2 * (192 + 64), 2500.0, "bf16x3 x bf16x3 products (operand-exact), f32 accumulate"
     tflops = flop_per_sample * B * T / kern_s / 1e12
     # algorithmic bytes of the dominant launch: x in + y out, + the target it reads when the loss leg rides in it
     bytes_per_sample = BYTES_PER_SAMPLE + (4 if fused_esr else 0)
@@ -1134,7 +1172,8 @@ def main():
                 "frac": tflops / peak_tflops, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes": float(bytes_per_sample) * B * T,
                 "kernel": {"auto": "gru_mfma2_kernel", "mfma2": "gru_mfma2_kernel", "mfma": "gru_mfma_kernel",
-                           "valu": "gru_valu_kernel", "f16x3": "gru_mfma2_kernel<f16x3>", "mfma4": "gru_mfma4_kernel"}[a.variant]
+                           "valu": "gru_valu_kernel", "f16x3": "gru_mfma2_kernel<f16x3>", "mfma4": "gru_mfma4_kernel",
+                           "bf16x3": "gru_mfma2_kernel<bf16x3>"}[a.variant]
                           + ("<ESR: forward + loss sums>" if fused_esr else ""),
                 "kernel_ms": 1e3 * kern_s, "flop_per_sample": flop_per_sample, "per": "GPU (rank 0's launch)",
                 "segments_in_launch": B,

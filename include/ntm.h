@@ -32,7 +32,7 @@ extern "C" {
 #define NTM_EHIP (-2)    /* HIP runtime error (launch failed, no device)               */
 #define NTM_EDELAY (-3)  /* reserved for host-side delay-range checks                  */
 
-#define NTM_ABI_VERSION 8 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag.  3: the TCN scratch is padded (ntm_tcn_scratch_floats grew), dilation / length limits.  4: ntm_diffdel_gru_forward is ONE fused launch where the matrix-pipe kernel runs (+ ntm_diffdel_gru_forward_ex).  5: ntm_gru_forward_esr, ntm_diffdel_gru_forward_esr.  6: ntm_tcn_forward works through the batch in stream chunks, ntm_tcn_scratch_floats is bounded (<= 2.0e9 floats + padding for any B), ntm_tcn_chunk_streams; DiffDelGRU warm-up calls always take the two-pass form.  7: ntm_loss_scalars (+ include/ntm_rccl.h, libntm_rccl.so).  8: any hidden size in [1, NTM_MAX_HIDDEN]; ntm_gru_forward_losses / ntm_diffdel_gru_forward_losses (ESR + DCPreESR sums in the recurrent launch) */
+#define NTM_ABI_VERSION 9 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag.  3: the TCN scratch is padded (ntm_tcn_scratch_floats grew), dilation / length limits.  4: ntm_diffdel_gru_forward is ONE fused launch where the matrix-pipe kernel runs (+ ntm_diffdel_gru_forward_ex).  5: ntm_gru_forward_esr, ntm_diffdel_gru_forward_esr.  6: ntm_tcn_forward works through the batch in stream chunks, ntm_tcn_scratch_floats is bounded (<= 2.0e9 floats + padding for any B), ntm_tcn_chunk_streams; DiffDelGRU warm-up calls always take the two-pass form.  7: ntm_loss_scalars (+ include/ntm_rccl.h, libntm_rccl.so).  8: any hidden size in [1, NTM_MAX_HIDDEN]; ntm_gru_forward_losses / ntm_diffdel_gru_forward_losses (ESR + DCPreESR sums in the recurrent launch).  9: NTM_GRU_BF16X3 */
 
 #define NTM_HIDDEN 64 /* hidden size of every shipped checkpoint (HS[64]): matrix-pipe and low-latency kernels.
                          Every other H in [1, NTM_MAX_HIDDEN] (the reference's `--HIDDEN_SIZE` is a free integer,
@@ -44,7 +44,7 @@ extern "C" {
 #define NTM_MAX_HIDDEN 1024
 
 /* GRU kernel variants.  ntm_gru_forward_ex of libntm.so (the product) accepts NTM_GRU_AUTO, _MFMA2,
- * _LAT and the opt-in _F16X3; the others are LABORATORY kernels -- older or experimental exact-fp32 implementations
+ * _LAT and the opt-in _F16X3 / _BF16X3; the others are LABORATORY kernels -- older or experimental exact-fp32 implementations
  * kept as independent checks and as measured dead ends -- compiled into libntm_lab.so only (include/ntm_lab.h).  */
 #define NTM_GRU_AUTO 0  /* NTM_GRU_MFMA2, or NTM_GRU_LAT when B <= NTM_GRU_LAT_MAX_B         */
 #define NTM_GRU_MFMA 1  /* 16 streams / workgroup, 4 waves, v_mfma_f32_16x16x4_f32, h in LDS */
@@ -56,6 +56,9 @@ extern "C" {
                            between waves (h feeds the next step from the registers it was computed in, BLGP-routed) */
 #define NTM_GRU_LAT_MAX_B 1024
 #define NTM_GRU_F16X3 4 /* OPT-IN: MFMA2 with W.h as three fp16 hi/lo products, fp32 accumulate  */
+#define NTM_GRU_BF16X3 8 /* OPT-IN: MFMA2 with W and h each split into THREE bf16 pieces (24 bits: the fp32 operands exactly) and
+                            W.h as their eight partial products W_p.h_q, p + q <= 3 (W_3.h_3 <= 2^-32 |W||h| is dropped), each exact
+                            in fp32, on v_mfma_f32_16x16x32_bf16 with fp32 accumulation; state, gates and head in fp32 as MFMA2 */
 
 /* ABI version of this header; bumped on any signature change. */
 int ntm_abi_version(void);

@@ -11,9 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NTM_LIB_PATH") or os.path.join(_HERE, "libntm.so")   # override: kernel A/B builds
 LAB_PATH = os.environ.get("NTM_LAB_PATH") or os.path.join(_HERE, "libntm_lab.so")   # laboratory kernels + diagnostics
 
-NTM_GRU_AUTO, NTM_GRU_MFMA, NTM_GRU_VALU, NTM_GRU_MFMA2, NTM_GRU_F16X3, NTM_GRU_MFMA3, NTM_GRU_LAT, NTM_GRU_MFMA4 = 0, 1, 2, 3, 4, 5, 6, 7
+NTM_GRU_AUTO, NTM_GRU_MFMA, NTM_GRU_VALU, NTM_GRU_MFMA2, NTM_GRU_F16X3, NTM_GRU_MFMA3, NTM_GRU_LAT, NTM_GRU_MFMA4, NTM_GRU_BF16X3 = 0, 1, 2, 3, 4, 5, 6, 7, 8
 VARIANTS = {"auto": NTM_GRU_AUTO, "mfma": NTM_GRU_MFMA, "valu": NTM_GRU_VALU, "mfma2": NTM_GRU_MFMA2,
-            "f16x3": NTM_GRU_F16X3, "mfma3": NTM_GRU_MFMA3, "lat": NTM_GRU_LAT, "mfma4": NTM_GRU_MFMA4}
+            "f16x3": NTM_GRU_F16X3, "mfma3": NTM_GRU_MFMA3, "lat": NTM_GRU_LAT, "mfma4": NTM_GRU_MFMA4, "bf16x3": NTM_GRU_BF16X3}
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -67,7 +67,7 @@ LAB_VARIANTS = ("mfma", "valu", "mfma3", "mfma4")
 
 _lib = None
 _lab = None
-ABI_VERSION = 8          # include/ntm.h NTM_ABI_VERSION this binding was written against
+ABI_VERSION = 9          # include/ntm.h NTM_ABI_VERSION this binding was written against
 HIDDEN_SIZES = (8, 16, 32, 64)      # sizes with a kernel of their own; every H in [1, MAX_HIDDEN] runs (include/ntm.h)
 MAX_HIDDEN = 1024
 NTM_DIFFDEL_AUTO, NTM_DIFFDEL_TWO_PASS, NTM_DIFFDEL_FUSED = 0, 1, 2
@@ -110,7 +110,7 @@ def lib():
 
 def lab():
     """libntm_lab.so: the laboratory kernels (kernel_variant in LAB_VARIANTS) and the diagnostic entry points.  The
-    product path (kernel_variant "auto" / "mfma2" / "lat" / "f16x3") never loads it."""
+    product path (kernel_variant "auto" / "mfma2" / "lat" / "f16x3" / "bf16x3") never loads it."""
     global _lab
     if _lab is None:
         if not os.path.exists(LAB_PATH):

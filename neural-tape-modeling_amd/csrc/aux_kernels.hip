@@ -27,7 +27,7 @@ namespace ntm {
 // through delay_sample().  HBM-bound pass: 12 B/sample (d, x once, y).  Sample indices inside a stream are 32-bit
 // (T < 2^31) and the classification avoids float -> int64 conversions: at 4 samples per thread the pass is as much
 // instruction-bound as memory-bound.
-// History of the shape at 4096 x 65 536, D = 1847 (tools/delay_probe.py; torch's two-in one-out elementwise add, the
+// History of the shape at 4096 x 65 536, D = 1847 (tools/attic/delay_probe.py; torch's two-in one-out elementwise add, the
 // same traffic, takes 0.54 ms): four launches with a separate range-check pass ~1.5 ms | one pass, 8 consecutive
 // samples per thread (32-byte lane stride) 1.03 | 4 per thread, two runs per workgroup 0.89 | XCD-aware ids 0.85 |
 // a loop of 8 runs per workgroup with the next d prefetched 0.99 (worse: dropped) | 32-bit lean classification with

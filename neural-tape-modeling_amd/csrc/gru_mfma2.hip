@@ -52,8 +52,11 @@ constexpr int HB = 4 * HB_K;      // 1280 floats per buffer
 constexpr int XS = TT + 1;        // x tile row (conflict-free column reads)
 constexpr int YS = TT + 4;        // y partial row: 16-B aligned rows for ds_read_b128 at flush
 constexpr int YP_Q = SG * YS;     // 1088 floats per partial plane
-constexpr int smem_floats(int ypn) { return 2 * HB + 2 * SG * XS + 2 * ypn * YP_Q; }   // ypn partial planes per y tile
-static_assert((2 * HB + 2 * SG * XS) % 4 == 0 && YS % 4 == 0 && YP_Q % 4 == 0, "y partial rows must be 16-B aligned");
+constexpr int HB3 = 2 * 3 * 64 * 4; // ENGINE 2 exchange buffer: [K half][bf16 piece][lane] x 16 B = 1536 floats
+constexpr int hb_floats(int engine) { return engine == 2 ? HB3 : HB; }
+constexpr int smem_floats(int ypn, int engine = 0) { return 2 * hb_floats(engine) + 2 * SG * XS + 2 * ypn * YP_Q; }   // ypn partial planes per y tile
+static_assert((2 * HB + 2 * SG * XS) % 4 == 0 && (2 * HB3 + 2 * SG * XS) % 4 == 0 && YS % 4 == 0 && YP_Q % 4 == 0,
+              "y partial rows must be 16-B aligned");
 }  // namespace m2
 
 __device__ __forceinline__ f32x4 mfma16x(float a, float b, f32x4 c)
@@ -96,6 +99,21 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// fp32 pair -> three bf16 pairs, round to nearest each time: v = p0 + p1 + p2 EXACTLY (8 + 8 + 8 significant bits, the
+// residuals v - p0 and v - p0 - p1 are exact in fp32; bf16 has fp32's exponent range).  v_cvt_pk_bf16_f32 packs a pair
+// into one dword; 9 vector instructions per pair.
+__device__ __forceinline__ void split_bf16x3(const f32x2 v, bf16x2 &p0, bf16x2 &p1, bf16x2 &p2)
+{
+    p0 = __builtin_convertvector(v, bf16x2);
+    const f32x2 r1 = v - __builtin_convertvector(p0, f32x2);
+    p1 = __builtin_convertvector(r1, bf16x2);
+    const f32x2 r2 = r1 - __builtin_convertvector(p1, f32x2);
+    p2 = __builtin_convertvector(r2, bf16x2);
+}
 
 // fp32 x4 -> fp16 hi + fp16 lo (round to nearest both times): v = hi + lo to ~22 bits
 __device__ __forceinline__ void split_f16(const f32x4 v, f16x4 &hi, f16x4 &lo)
@@ -130,6 +148,19 @@ __device__ __forceinline__ f32x4 pack_hl(const f16x4 hi, const f16x4 lo)
 //   the same as ENGINE 0's.  Per step and wave 27 MFMAs of ~17 cycles instead of 48 x 32:
 //   own quarter 9 x K16, the two other quarters that are adjacent in the exchange row as 9 x K32
 //   (v_mfma_f32_16x16x32_f16), the remaining quarter 9 x K16.
+// ENGINE 2: "bf16x3" -- W and h are each split into THREE bf16 pieces (24 significant bits: the fp32 operands exactly, over
+//   fp32's exponent range) and W.h is the sum of the partial products W_p.h_q, p + q <= 3 of {1,2,3} (all nine but W_3.h_3,
+//   which is <= 2^-32 of |W||h|: 1/256 of ONE fp32 rounding of the product), each exact in fp32, on
+//   v_mfma_f32_16x16x32_bf16 with fp32 accumulation: 8 products x 2 K halves x 3 gates = 48 MFMAs of ~16 cycles per wave
+//   and step instead of 48 x 32.  The bf16 matrix pipe leaves half of its cycles to the vector pipe (the fp32 one does not),
+//   so the r and n gate math is issued INSIDE the MFMA block; the step has its own order (step_b below):
+//     barrier 1 (the hi pieces of h_{t-1} are visible) -> ds_read hi; in the shadow of that round trip the mid / lo pieces
+//     are formed and published, the head partial of y_{t-1} parked -> 18 MFMAs on the hi pieces -> barrier 2 -> ds_read
+//     mid / lo -> 30 MFMAs (r chain, n chain with the r sigmoid in its gaps, z chain with the n gate in its gaps) -> z
+//     sigmoid, blend -> hi piece of h_t published.
+//   Exchange layout: buffer[K half m][piece p][lane l] = 16 B = [quarter 2m: units 4q..4q+3 | quarter 2m+1: the same] of
+//   stream j (l = 16 q + j) -- the B operand of the K = 32 MFMA as ONE conflict-free ds_read_b128; wave w writes its 8 bytes
+//   at half w >> 1, offset 8 (w & 1).  Everything outside the GEMV (state, gates, head) is ENGINE 0's fp32 code.
 // YPN = 16: every lane parks its 4-unit head partial (16 planes per y tile, 152 KB of LDS, one workgroup per
 //   CU -- right for B <= 4096 where a CU has a single 16-stream group anyway).
 // YPN = 4: the four lane groups of a wave are summed first (two permlane swaps), 4 planes, 53 KB of LDS:
@@ -170,6 +201,9 @@ __device__ __forceinline__ f32x4 pack_hl(const f16x4 hi, const f16x4 lo)
 #ifndef NTM_TANH_FORM
 #define NTM_TANH_FORM 0
 #endif
+#ifndef NTM3_ASM
+#define NTM3_ASM 1        // ENGINE 2: the hand-scheduled MFMA / gate block (0: the compiler-scheduled form, same arithmetic, for the A/B)
+#endif
 template <bool PRESCALE, bool STAMP, int ABL = 0, int ENGINE = 0, int YPN = 16, bool FUSE = false, bool ESR = false, bool DCP = false>
 __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 {
@@ -177,8 +211,8 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     unsigned long long seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = 0, ts_[6];    // [6..11]: the phase-2 steps alone
     (void)seg; (void)last_; (void)ts_;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *hb = smem;                  // [2][4 k][16 stream][20]
-    float *xb = hb + 2 * HB;           // [2][16][65]
+    float *hb = smem;                  // [2][4 k][16 stream][20]      (ENGINE 2: [2][2 K halves][3 pieces][64 lanes][4])
+    float *xb = hb + 2 * hb_floats(ENGINE);   // [2][16][65]
     float *yp = xb + 2 * SG * XS;      // [2][16 (w,q)][16][68]   (offset 4640 floats: 16-B aligned)
 
     const int tid = threadIdx.x;
@@ -202,6 +236,8 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     float Ar[16], Az[16], An[16];
     f16x4 Ah[3][2], Al[3][2];
     f16x8 A8h[3], A8l[3];
+    // ENGINE 2: A3[g][m][p] = bf16 piece p of W_g[16w + (l&15)][16 (2m) + 4(l>>4) + 0..3 | 16 (2m+1) + 4(l>>4) + 0..3], g = r, n, z
+    bf16x8 A3[3][2][3];
     const int pa = (w < 2) ? 2 : 0;
     {
         const int row = 16 * w + j;
@@ -214,6 +250,24 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
                 const int s = (sg + 4 * w) & 15;
                 const int u0 = 16 * (s >> 2) + (s & 3);
                 Ar[sg] = pr[u0] * SRZ; Az[sg] = pz[u0] * SRZ; An[sg] = pn[u0] * SN;
+            }
+        } else if constexpr (ENGINE == 2) {
+            const float *pg[3] = {pr, pn, pz};
+            const float sc[3] = {SRZ, SN, SRZ};
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    bf16x2 p0[4], p1[4], p2[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {       // i = 0,1: quarter 2m, units 4q + 0..3;  i = 2,3: quarter 2m + 1
+                        const float *pq = pg[g] + 16 * (2 * m + (i >> 1)) + 2 * (i & 1);
+                        split_bf16x3((f32x2){pq[0] * sc[g], pq[1] * sc[g]}, p0[i], p1[i], p2[i]);
+                    }
+                    A3[g][m][0] = (bf16x8){p0[0][0], p0[0][1], p0[1][0], p0[1][1], p0[2][0], p0[2][1], p0[3][0], p0[3][1]};
+                    A3[g][m][1] = (bf16x8){p1[0][0], p1[0][1], p1[1][0], p1[1][1], p1[2][0], p1[2][1], p1[3][0], p1[3][1]};
+                    A3[g][m][2] = (bf16x8){p2[0][0], p2[0][1], p2[1][0], p2[1][1], p2[2][0], p2[2][1], p2[3][0], p2[3][1]};
+                }
             }
         } else {
             const float *pg[3] = {pr, pn, pz};
@@ -541,7 +595,15 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     float hT[4] = {hold[0][0], hold[0][1], hold[1][0], hold[1][1]};
     f16x4 hTh, hTl;                      // ENGINE 1: the same four values as fp16 hi / lo parts
     split_f16((f32x4){hT[0], hT[1], hT[2], hT[3]}, hTh, hTl);
+    // ENGINE 2: the hi pieces of this lane's four units (packed pairs), formed when h_t is; its exchange addresses
+    bf16x2 h3hi[2];
+    h3hi[0] = __builtin_convertvector(hold[0], bf16x2);
+    h3hi[1] = __builtin_convertvector(hold[1], bf16x2);
+    float *const h3wr = hb + ((w >> 1) * 3 * 64 + l) * 4 + 2 * (w & 1);    // + 256 p + HB3 buffer (floats)
+    const float *const h3rd = hb + l * 4;                                  // + 256 (3 m + p) + HB3 buffer
+    (void)h3wr; (void)h3rd;
     if constexpr (ENGINE == 0) *(f32x4 *)&hb[0 * HB + q * HB_K + j * HB_J + 4 * w] = (f32x4){hT[0], hT[1], hT[2], hT[3]};
+    else if constexpr (ENGINE == 2) *(bf16x4 *)h3wr = (bf16x4){h3hi[0][0], h3hi[0][1], h3hi[1][0], h3hi[1][1]};
     else {
         // ENGINE 1 exchange row (kg, j): [hi q0 | hi q1 | hi q2 | hi q3 | lo q0 | lo q1 | lo q2 | lo q3], 8 B each
         *(f16x4 *)&hb[0 * HB + q * HB_K + j * HB_J + 2 * w] = hTh;
@@ -568,6 +630,75 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     float *const hrow = hb + q * HB_K + j * HB_J;   // ENGINE 1 addressing
     const int ps = w ^ 1;
 
+    // hk_c: tile housekeeping of a step, decided at COMPILE time in whole tiles (0 none, 1 the ph == 2 work, 2 the ph == 34
+    // work, 3 the ph == 36 work of FUSE) so that the step carries no phase tests; -1 = test ph at run time (ragged last tile)
+    auto housekeeping = [&](const int64_t t, const int ph, const int64_t tile, auto hk_c) __attribute__((always_inline)) {
+        constexpr int HK = decltype(hk_c)::value;
+        (void)t; (void)ph; (void)tile;
+    if constexpr (!(ABL & 32)) {
+        if (HK == 1 || (HK < 0 && ph == 2)) {
+            if constexpr (FUSE) {
+                // y of the tile whose taps were fetched at phase 36 of the previous tile, into registers; below, this
+                // tile's delays -- every load of the step ahead of every store.
+                // The wait is the BUILTIN (vmcnt(0) only: simm16 0x0F70 leaves expcnt / lgkmcnt alone) so that hipcc's
+                // own wait bookkeeping sees it: with the taps' consumers behind run-time stage tests it otherwise
+                // keeps "a load into these registers may be pending" alive around the loop and drains the VM counter
+                // in front of the NEXT loads -- the x tile fetched just before them, a full memory round trip.
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                if (__builtin_expect(dl_stage == 2, 1)) {
+                    dl_compute(std::bool_constant<(HK > 0)>{});
+                    // the loss leg of the DiffDelGRU step: the ESR terms of the tile whose y has just been formed
+                    if constexpr (ESR_DL) esr_accumulate(dl_tile, dl_out, std::bool_constant<(HK > 0)>{});
+                }
+            }
+            // the x loads go out before the flush's stores (no VMEM drain between them)
+            f32x4 fv = {0.0f, 0.0f, 0.0f, 0.0f};
+            if constexpr (ESR_FLUSH) {
+                // the flushed tile's sums and its ESR terms first: they consume the target fetched one tile ago, and
+                // nothing newer may be in flight when hipcc waits for it (it waits for everything)
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                if (__builtin_expect(t > 65, 1)) {
+                    fv = flush_sum(next_flush);
+                    esr_accumulate(next_flush, fv, std::bool_constant<(HK > 0)>{});
+                }
+            }
+#if NTM2_HKTRIM
+            if (__builtin_expect((tile + 2) * TT <= T, 1)) load_x_tile_whole(tile + 1, xr);
+            else if ((tile + 1) * TT < T) load_x_tile(tile + 1, xr);
+#else
+            if (__builtin_expect((tile + 1) * TT < T, 1)) load_x_tile(tile + 1, xr);
+#endif
+            if constexpr (ESR_FLUSH) {
+                // the next flush's target (tile next_flush + 1 = this tile when t > 65): whole inside the unrolled loop
+                if (__builtin_expect(t > 65, 1)) {
+                    if (HK > 0) esr_fetch_whole(next_flush + 1);
+                    flush_store(next_flush, fv, std::bool_constant<(HK > 0)>{});
+                    ++next_flush;
+                }
+            }
+            if constexpr (FUSE) {
+                if (__builtin_expect(dl_on && t > 65, 1)) {
+                    dl_load_d((int)next_flush, std::bool_constant<(HK > 0)>{});
+                    if constexpr (ESR_DL) {
+                        if (HK > 0) esr_fetch_whole(next_flush);       // the target of the delay tile now in flight
+                    }
+                }
+                dl_store();
+            }
+            if constexpr (!ESR_FLUSH) {
+                if (__builtin_expect(t > 65, 1)) { flush_y_tile(next_flush, std::bool_constant<(HK > 0)>{}); ++next_flush; }
+            }
+        } else if (HK == 2 || (HK < 0 && ph == 34)) {
+            if (__builtin_expect((tile + 1) * TT < T, 1)) store_x_tile(tile + 1, xr);
+            // FUSE: this thread's pre_d stores of phase 2 have completed; step 35's barrier makes that true of the
+            // whole workgroup before phase 36 reads them back
+            if constexpr (FUSE) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), as a MachineInstr hipcc accounts for
+        } else if (FUSE && (HK == 3 || (HK < 0 && ph == 36))) {
+            if (__builtin_expect(dl_stage == 1, 1)) dl_issue_taps(std::bool_constant<(HK > 0)>{});
+        }
+    }
+
+    };
     if constexpr (STAMP) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(last_)::"memory");
     // hk_c: tile housekeeping of this step, decided at COMPILE time in whole tiles (0 none, 1 the ph == 2 work,
     // 2 the ph == 34 work) so that the step carries no phase tests; -1 = test ph at run time (ragged last tile)
@@ -686,68 +817,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 
         // tile housekeeping, once per 64 steps each (y partials of the previous tile are complete and
         // visible once step 64i+65 has passed its barrier)
-        if constexpr (!(ABL & 32)) {
-            if (HK == 1 || (HK < 0 && ph == 2)) {
-                if constexpr (FUSE) {
-                    // y of the tile whose taps were fetched at phase 36 of the previous tile, into registers; below, this
-                    // tile's delays -- every load of the step ahead of every store.
-                    // The wait is the BUILTIN (vmcnt(0) only: simm16 0x0F70 leaves expcnt / lgkmcnt alone) so that hipcc's
-                    // own wait bookkeeping sees it: with the taps' consumers behind run-time stage tests it otherwise
-                    // keeps "a load into these registers may be pending" alive around the loop and drains the VM counter
-                    // in front of the NEXT loads -- the x tile fetched just before them, a full memory round trip.
-                    __builtin_amdgcn_s_waitcnt(0x0F70);
-                    if (__builtin_expect(dl_stage == 2, 1)) {
-                        dl_compute(std::bool_constant<(HK > 0)>{});
-                        // the loss leg of the DiffDelGRU step: the ESR terms of the tile whose y has just been formed
-                        if constexpr (ESR_DL) esr_accumulate(dl_tile, dl_out, std::bool_constant<(HK > 0)>{});
-                    }
-                }
-                // the x loads go out before the flush's stores (no VMEM drain between them)
-                f32x4 fv = {0.0f, 0.0f, 0.0f, 0.0f};
-                if constexpr (ESR_FLUSH) {
-                    // the flushed tile's sums and its ESR terms first: they consume the target fetched one tile ago, and
-                    // nothing newer may be in flight when hipcc waits for it (it waits for everything)
-                    __builtin_amdgcn_s_waitcnt(0x0F70);
-                    if (__builtin_expect(t > 65, 1)) {
-                        fv = flush_sum(next_flush);
-                        esr_accumulate(next_flush, fv, std::bool_constant<(HK > 0)>{});
-                    }
-                }
-#if NTM2_HKTRIM
-                if (__builtin_expect((tile + 2) * TT <= T, 1)) load_x_tile_whole(tile + 1, xr);
-                else if ((tile + 1) * TT < T) load_x_tile(tile + 1, xr);
-#else
-                if (__builtin_expect((tile + 1) * TT < T, 1)) load_x_tile(tile + 1, xr);
-#endif
-                if constexpr (ESR_FLUSH) {
-                    // the next flush's target (tile next_flush + 1 = this tile when t > 65): whole inside the unrolled loop
-                    if (__builtin_expect(t > 65, 1)) {
-                        if (HK > 0) esr_fetch_whole(next_flush + 1);
-                        flush_store(next_flush, fv, std::bool_constant<(HK > 0)>{});
-                        ++next_flush;
-                    }
-                }
-                if constexpr (FUSE) {
-                    if (__builtin_expect(dl_on && t > 65, 1)) {
-                        dl_load_d((int)next_flush, std::bool_constant<(HK > 0)>{});
-                        if constexpr (ESR_DL) {
-                            if (HK > 0) esr_fetch_whole(next_flush);       // the target of the delay tile now in flight
-                        }
-                    }
-                    dl_store();
-                }
-                if constexpr (!ESR_FLUSH) {
-                    if (__builtin_expect(t > 65, 1)) { flush_y_tile(next_flush, std::bool_constant<(HK > 0)>{}); ++next_flush; }
-                }
-            } else if (HK == 2 || (HK < 0 && ph == 34)) {
-                if (__builtin_expect((tile + 1) * TT < T, 1)) store_x_tile(tile + 1, xr);
-                // FUSE: this thread's pre_d stores of phase 2 have completed; step 35's barrier makes that true of the
-                // whole workgroup before phase 36 reads them back
-                if constexpr (FUSE) __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), as a MachineInstr hipcc accounts for
-            } else if (FUSE && (HK == 3 || (HK < 0 && ph == 36))) {
-                if (__builtin_expect(dl_stage == 1, 1)) dl_issue_taps(std::bool_constant<(HK > 0)>{});
-            }
-        }
+        housekeeping(t, ph, tile, hk_c);
 
         // ---- the VALU block ------------------------------------------------------------------------
         // input terms of step t+1 first: they do not wait for the last MFMAs to drain
@@ -779,7 +849,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
             f32x2 pn = __builtin_elementwise_fma(r, an, gi[p]);        // (2 log2e) (gi_n + r gh_n) if PRESCALE
             if (!PRESCALE) pn *= 2.0f * LOG2E;
 #if NTM_TANH_FORM == 1
-            // EXPERIMENT (never in libntm.so: `make exp` builds libntm_tanh1.so for tools/tanh_form_probe.py): tanh as
+            // EXPERIMENT (never in libntm.so: `make exp` builds libntm_tanh1.so for tools/attic/tanh_form_probe.py): tanh as
             // sign(p) (1 - t) rcp(1 + t), t = 2^-|p| <= 1 -- no cancellation for small |n| (tools/ubench/gate_ulp.hip: abs.
             // error 1.35e-8 instead of 4.6e-8 there), no overflow; costs one packed op and two v_bfi_b32 per pair more.
             const f32x2 tn = {__builtin_amdgcn_exp2f(-__builtin_fabsf(pn[0])), __builtin_amdgcn_exp2f(-__builtin_fabsf(pn[1]))};
@@ -843,6 +913,362 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
             last_ = ts_[5];
         }
     };
+    // ---- ENGINE 2: the step in its own order (comment above the kernel) ------------------------------------------------
+    // head partial of y_{tp} over this lane's four units of h_{tp} (= hold), parked for the tile flush
+    auto park_head = [&](const int64_t tp) __attribute__((always_inline)) {
+        const f32x2 pp = __builtin_elementwise_fma(hold[1], wo[1], hold[0] * wo[0]);
+        float hp = pp[0] + pp[1];
+        if constexpr (YPN == 4) {       // as in step(): the wave's four lane groups summed, all four store the same value
+            float hq;
+            asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(hp), "=&v"(hq));
+            hp += hq;
+            asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(hp), "=&v"(hq));
+            hp += hq;
+        }
+        yp_lane[(int)((tp >> 6) & 1) * YPN * YP_Q + (int)(tp & 63)] = hp;
+    };
+#define NTM3_MF(ACC, G, M, P, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A3[G][M][P], B, ACC, 0, 0, 0)
+    (void)step;
+#if NTM3_ASM
+    // state of the asm form (held in fixed registers inside step_b): the fp32 h of this lane's four units and its packed hi
+    // pieces; the seeds of the r / z accumulators (the input terms of the step they will run; step 0: from the prologue); the
+    // accumulators and the six B operands in flight between the statements; LDS byte addresses for the ds_* inside the strings
+    typedef const __attribute__((address_space(3))) float *lds_cptr;
+    f32x4 h4 = {hold[0][0], hold[0][1], hold[1][0], hold[1][1]};
+    f32x2 p0v = __builtin_bit_cast(f32x2, (bf16x4){h3hi[0][0], h3hi[0][1], h3hi[1][0], h3hi[1][1]});
+    // (step 0 is an even step: it reads parity 0 of the seed / gi_n pairs)
+    f32x4 seed_r = {cr[0][0], cr[0][1], cr[1][0], cr[1][1]};
+    f32x4 seed_z[2] = {{cz[0][0], cz[0][1], cz[1][0], cz[1][1]}, {0.0f, 0.0f, 0.0f, 0.0f}};
+    f32x4 gi4[2] = {{gi[0][0], gi[0][1], gi[1][0], gi[1][1]}, {0.0f, 0.0f, 0.0f, 0.0f}};
+    const f32x4 bhn4 = {bhn[0][0], bhn[0][1], bhn[1][0], bhn[1][1]};
+    const f32x4 wir4 = {wir[0][0], wir[0][1], wir[1][0], wir[1][1]}, br4 = {br[0][0], br[0][1], br[1][0], br[1][1]};
+    const f32x4 wiz4 = {wiz[0][0], wiz[0][1], wiz[1][0], wiz[1][1]}, bz4 = {bz[0][0], bz[0][1], bz[1][0], bz[1][1]};
+    const f32x4 win4 = {win[0][0], win[0][1], win[1][0], win[1][1]}, bin4 = {bin_[0][0], bin_[0][1], bin_[1][0], bin_[1][1]};
+    const f32x4 wo4 = {wo[0][0], wo[0][1], wo[1][0], wo[1][1]};
+    f32x4 acc3[3];
+    bf16x8 B3[6];
+    const unsigned rd_addr = (unsigned)(uintptr_t)(lds_cptr)h3rd, wr_addr = (unsigned)(uintptr_t)(lds_cptr)h3wr;
+    const unsigned yp_addr = (unsigned)(uintptr_t)(lds_cptr)yp_lane;
+    (void)gi4; (void)wir4; (void)br4; (void)wiz4; (void)bz4; (void)win4; (void)bin4; (void)wo4;
+    (void)h4; (void)p0v; (void)seed_r; (void)seed_z; (void)bhn4; (void)acc3; (void)B3; (void)rd_addr; (void)wr_addr; (void)yp_addr;
+#endif
+    auto step_b = [&](const int64_t t, auto cur_c, auto hk_c) {
+#if NTM3_ASM
+        // ---- the hand-scheduled form: four asm statements from barrier 1 to the publication of h_t's hi piece.  The step is
+        //      paced by the matrix pipe, and which vector instruction sits in which MFMA gap decides its length
+        //      (tools/ubench/mfma_bf16_gap.hip, cycles per v_mfma_f32_16x16x32_bf16 of one wave: alone 17.6; + one v_exp_f32
+        //      18.3; + two v_add_f32 / v_fma_f32 18.5; + v_exp_f32 + v_add_f32 22.6; + four v_add_f32 26.6; + ONE
+        //      v_pk_add_f32 34.5 -- packed fp32 ops do not overlap a bf16 MFMA at all, so the gaps hold only plain ops, at most
+        //      one transcendental or two simple ones each; the compiler-scheduled form below, with packed ops and hipcc's
+        //      own wait states around MFMA results, runs ~1690 cycles per step).
+        //      Order of the 48 MFMAs: r hi (1) | barrier 2, ds_read mid / lo | r hi (5), n hi (6); r mid+lo (10)
+        //      [the input terms of step t+1, the head partial of y_{t-1}]; n mid+lo (10) [r sigmoid]; z hi + mid + lo (16)
+        //      [n gate]; then the z sigmoid, the blend, the hi piece of h_t.  Per accumulator the order of the products is the
+        //      compiler form's, so the two forms agree bit for bit (tests/test_gpu_round6.py).
+        //      Registers: the strings name single elements of tuples, which asm operands cannot express, so everything they
+        //      touch lives in FIXED registers, declared to hipcc as physical-register operands / clobbers:
+        //        v[100:103] acc r -> r     v[104:107] acc n     v[108:111] acc z       v[112:115] n gate    v[116:119] h - n
+        //        v[120:123] z sigmoid      v[124:127] h (fp32)  v[128:129] hi pieces   v[130:133] mid, lo   v[134:141] scratch
+        //        v[142:165] B operands (hi, mid, lo x 2 K halves)    v[166:169] seed of the r accumulator (W_ir x + b)
+        //        v[170:173] / v[210:213] seed of the z accumulator and v[174:177] / v[206:209] gi_n, by step parity (the
+        //        values of step t+1 are formed before step t has used its own)    v[178:205] W_ih, biases, head weights
+        //      Waits inside the strings are by hand: lgkmcnt(0) only (LDS returns in order, so an LDS op hipcc has in flight
+        //      is harmless); MFMA result -> vector read >= 28 cycles after the MFMA's issue; transcendental result -> next
+        //      vector use one state later; permlane swaps as in park_head.
+        constexpr int cur = decltype(cur_c)::value;   // == t & 1: which exchange buffer holds h_{t-1}
+        static_assert(PRESCALE, "the asm form of the bf16x3 step folds the log2(e) factors into the weights");
+        const int ph = (int)(t & 63);
+        const int64_t tile = t >> 6;
+        NTM2_STAMP(0)
+        housekeeping(t, ph, tile, hk_c);
+        // (hipcc-issued, retired by the first statement's wait) x of step t+1; the slot the head partial of y_{t-1} parks in
+        const float xn = xb[(((t + 1) >> 6) & 1) * SG * XS + j * XS + (int)((t + 1) & 63)];
+        const unsigned ya = yp_addr + 4u * (unsigned)((int)(((t - 1) >> 6) & 1) * YPN * YP_Q + (int)((t - 1) & 63));
+        NTM2_STAMP(1)
+#define MF3(D, A, B, C) "v_mfma_f32_16x16x32_bf16 " D ", " A ", " B ", " C "\n\t"
+#define NEG " neg_lo:[0,1] neg_hi:[0,1]\n\t"
+#define FMA(D, A, B, C) "v_fma_f32 " D ", " A ", " B ", " C "\n\t"
+#define NTM3_S1(O_H0, O_H1, O_M0, O_M1, O_L0, O_L1, O_WM, O_WL)                                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\t"                                                                      \
+                     "ds_read_b128 v[142:145], %[rd] offset:" O_H0 "\n\tds_read_b128 v[146:149], %[rd] offset:" O_H1 "\n\t"      \
+                     "v_lshlrev_b32 v134, 16, v128\n\tv_and_b32 v135, 0xffff0000, v128\n\t"                                        \
+                     "v_lshlrev_b32 v136, 16, v129\n\tv_and_b32 v137, 0xffff0000, v129\n\t"                                        \
+                     "v_pk_add_f32 v[138:139], v[124:125], v[134:135]" NEG "v_pk_add_f32 v[140:141], v[126:127], v[136:137]" NEG   \
+                     "v_cvt_pk_bf16_f32 v130, v138, v139\n\tv_cvt_pk_bf16_f32 v131, v140, v141\n\t"                                \
+                     "v_lshlrev_b32 v134, 16, v130\n\tv_and_b32 v135, 0xffff0000, v130\n\t"                                        \
+                     "v_lshlrev_b32 v136, 16, v131\n\tv_and_b32 v137, 0xffff0000, v131\n\t"                                        \
+                     "v_pk_add_f32 v[138:139], v[138:139], v[134:135]" NEG "v_pk_add_f32 v[140:141], v[140:141], v[136:137]" NEG   \
+                     "v_cvt_pk_bf16_f32 v132, v138, v139\n\tv_cvt_pk_bf16_f32 v133, v140, v141\n\t"                                \
+                     "ds_write_b64 %[wr], v[130:131] offset:" O_WM "\n\tds_write_b64 %[wr], v[132:133] offset:" O_WL "\n\t"      \
+                     "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
+                     MF3("v[100:103]", "%[r00]", "v[142:145]", "v[166:169]")                                                       \
+                     "s_barrier\n\t"                                                                                              \
+                     "ds_read_b128 v[150:153], %[rd] offset:" O_M0 "\n\tds_read_b128 v[154:157], %[rd] offset:" O_M1 "\n\t"      \
+                     "ds_read_b128 v[158:161], %[rd] offset:" O_L0 "\n\tds_read_b128 v[162:165], %[rd] offset:" O_L1 "\n\t"      \
+                     MF3("v[100:103]", "%[r10]", "v[146:149]", "v[100:103]")                                                       \
+                     MF3("v[104:107]", "%[n00]", "v[142:145]", "%[bhn]") MF3("v[104:107]", "%[n10]", "v[146:149]", "v[104:107]")  \
+                     MF3("v[100:103]", "%[r01]", "v[142:145]", "v[100:103]") MF3("v[100:103]", "%[r11]", "v[146:149]", "v[100:103]") \
+                     MF3("v[100:103]", "%[r02]", "v[142:145]", "v[100:103]") MF3("v[100:103]", "%[r12]", "v[146:149]", "v[100:103]") \
+                     MF3("v[104:107]", "%[n01]", "v[142:145]", "v[104:107]") MF3("v[104:107]", "%[n11]", "v[146:149]", "v[104:107]") \
+                     MF3("v[104:107]", "%[n02]", "v[142:145]", "v[104:107]") "v_mfma_f32_16x16x32_bf16 v[104:107], %[n12], v[146:149], v[104:107]" \
+                     : "=&{v[100:103]}"(acc3[0]), "=&{v[104:107]}"(acc3[1]), "=&{v[142:145]}"(B3[0]), "=&{v[146:149]}"(B3[1]),      \
+                       "=&{v[150:153]}"(B3[2]), "=&{v[154:157]}"(B3[3]), "=&{v[158:161]}"(B3[4]), "=&{v[162:165]}"(B3[5])          \
+                     : [rd] "v"(rd_addr), [wr] "v"(wr_addr), "{v[166:169]}"(seed_r), "{v[124:127]}"(h4), "{v[128:129]}"(p0v),      \
+                       [bhn] "v"(bhn4), [r00] "v"(A3[0][0][0]), [r10] "v"(A3[0][1][0]), [r01] "v"(A3[0][0][1]), [r11] "v"(A3[0][1][1]), \
+                       [r02] "v"(A3[0][0][2]), [r12] "v"(A3[0][1][2]), [n00] "v"(A3[1][0][0]), [n10] "v"(A3[1][1][0]),             \
+                       [n01] "v"(A3[1][0][1]), [n11] "v"(A3[1][1][1]), [n02] "v"(A3[1][0][2]), [n12] "v"(A3[1][1][2])              \
+                     : "memory", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141")
+        if constexpr (cur == 0) NTM3_S1("0", "3072", "1024", "4096", "2048", "5120", "1024", "2048");
+        else NTM3_S1("6144", "9216", "7168", "10240", "8192", "11264", "7168", "8192");
+#undef NTM3_S1
+        NTM2_STAMP(2)
+        // r chain, mid and lo pieces; in its gaps, two plain ops each: the input terms of step t+1 (seeds of its r and z
+        // accumulators, gi_n) and the head partial of y_{t-1} over this lane's four units of h_{t-1}
+#define NTM3_S2(SZN, SZN0, SZN1, SZN2, SZN3, GIN, GIN0, GIN1, GIN2, GIN3, PARK)                                                     \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
+                     MF3("v[100:103]", "%[r00]", "v[150:153]", "v[100:103]") FMA("v166", "v178", "%[xn]", "v182") FMA("v167", "v179", "%[xn]", "v183") \
+                     MF3("v[100:103]", "%[r10]", "v[154:157]", "v[100:103]") FMA("v168", "v180", "%[xn]", "v184") FMA("v169", "v181", "%[xn]", "v185") \
+                     MF3("v[100:103]", "%[r01]", "v[150:153]", "v[100:103]") FMA(SZN0, "v186", "%[xn]", "v190") FMA(SZN1, "v187", "%[xn]", "v191")   \
+                     MF3("v[100:103]", "%[r11]", "v[154:157]", "v[100:103]") FMA(SZN2, "v188", "%[xn]", "v192") FMA(SZN3, "v189", "%[xn]", "v193")   \
+                     MF3("v[100:103]", "%[r02]", "v[150:153]", "v[100:103]") FMA(GIN0, "v194", "%[xn]", "v198") FMA(GIN1, "v195", "%[xn]", "v199")   \
+                     MF3("v[100:103]", "%[r12]", "v[154:157]", "v[100:103]") FMA(GIN2, "v196", "%[xn]", "v200") FMA(GIN3, "v197", "%[xn]", "v201")   \
+                     MF3("v[100:103]", "%[r00]", "v[158:161]", "v[100:103]") "v_mul_f32 v134, v124, v202\n\tv_mul_f32 v135, v125, v203\n\t"        \
+                     MF3("v[100:103]", "%[r10]", "v[162:165]", "v[100:103]") FMA("v134", "v126", "v204", "v134") FMA("v135", "v127", "v205", "v135") \
+                     MF3("v[100:103]", "%[r01]", "v[158:161]", "v[100:103]") PARK                                                  \
+                     : "+{v[100:103]}"(acc3[0]), "=&{v[166:169]}"(seed_r), "=&{" SZN "}"(seed_z[cur ^ 1]), "=&{" GIN "}"(gi4[cur ^ 1]) \
+                     : "{v[150:153]}"(B3[2]), "{v[154:157]}"(B3[3]), "{v[158:161]}"(B3[4]), "{v[162:165]}"(B3[5]),                 \
+                       [r00] "v"(A3[0][0][0]), [r10] "v"(A3[0][1][0]), [r01] "v"(A3[0][0][1]), [r11] "v"(A3[0][1][1]),             \
+                       [r02] "v"(A3[0][0][2]), [r12] "v"(A3[0][1][2]), [xn] "v"(xn), [ya] "v"(ya), "{v[124:127]}"(h4),             \
+                       "{v[178:181]}"(wir4), "{v[182:185]}"(br4), "{v[186:189]}"(wiz4), "{v[190:193]}"(bz4), "{v[194:197]}"(win4), \
+                       "{v[198:201]}"(bin4), "{v[202:205]}"(wo4)                                                                  \
+                     : "memory", "v134", "v135")
+        // (the park sequence ends the statement: the last sum, for YPN = 4 the two permlane swaps over the wave's four lane groups
+        //  -- all four then store the same value --, the store, and the chain's last MFMA)
+#define NTM3_PARK16 "v_add_f32 v134, v134, v135\n\tds_write_b32 %[ya], v134\n\t"                                                   \
+                    "v_mfma_f32_16x16x32_bf16 v[100:103], %[r11], v[162:165], v[100:103]"
+#define NTM3_PARK4 "v_add_f32 v134, v134, v135\n\tv_mov_b32 v135, v134\n\t"                                                        \
+                   MF3("v[100:103]", "%[r11]", "v[162:165]", "v[100:103]")                                                         \
+                   "s_nop 0\n\tv_permlane32_swap_b32 v134, v135\n\ts_nop 1\n\tv_add_f32 v134, v134, v135\n\tv_mov_b32 v135, v134\n\t" \
+                   "s_nop 1\n\tv_permlane16_swap_b32 v134, v135\n\ts_nop 1\n\tv_add_f32 v134, v134, v135\n\tds_write_b32 %[ya], v134"
+        if constexpr (cur == 0 && YPN == 16) NTM3_S2("v[210:213]", "v210", "v211", "v212", "v213", "v[206:209]", "v206", "v207", "v208", "v209", NTM3_PARK16);
+        else if constexpr (cur == 1 && YPN == 16) NTM3_S2("v[170:173]", "v170", "v171", "v172", "v173", "v[174:177]", "v174", "v175", "v176", "v177", NTM3_PARK16);
+        else if constexpr (cur == 0) NTM3_S2("v[210:213]", "v210", "v211", "v212", "v213", "v[206:209]", "v206", "v207", "v208", "v209", NTM3_PARK4);
+        else NTM3_S2("v[170:173]", "v170", "v171", "v172", "v173", "v[174:177]", "v174", "v175", "v176", "v177", NTM3_PARK4);
+#undef NTM3_S2
+#undef NTM3_PARK16
+#undef NTM3_PARK4
+        NTM2_STAMP(3)
+        // n chain, mid and lo pieces; from its second gap on the r sigmoid, in place: 4 x v_exp, 4 x v_add, 3 of the 4 x v_rcp
+        asm volatile(MF3("v[104:107]", "%[n00]", "v[150:153]", "v[104:107]")
+                     MF3("v[104:107]", "%[n10]", "v[154:157]", "v[104:107]") "v_exp_f32 v100, v100\n\t"
+                     MF3("v[104:107]", "%[n01]", "v[150:153]", "v[104:107]") "v_exp_f32 v101, v101\n\t"
+                     MF3("v[104:107]", "%[n11]", "v[154:157]", "v[104:107]") "v_exp_f32 v102, v102\n\t"
+                     MF3("v[104:107]", "%[n02]", "v[150:153]", "v[104:107]") "v_exp_f32 v103, v103\n\t"
+                     MF3("v[104:107]", "%[n12]", "v[154:157]", "v[104:107]") "v_add_f32 v100, 1.0, v100\n\tv_add_f32 v101, 1.0, v101\n\t"
+                     MF3("v[104:107]", "%[n00]", "v[158:161]", "v[104:107]") "v_add_f32 v102, 1.0, v102\n\tv_add_f32 v103, 1.0, v103\n\t"
+                     MF3("v[104:107]", "%[n10]", "v[162:165]", "v[104:107]") "v_rcp_f32 v100, v100\n\t"
+                     MF3("v[104:107]", "%[n01]", "v[158:161]", "v[104:107]") "v_rcp_f32 v101, v101\n\t"
+                     MF3("v[104:107]", "%[n11]", "v[162:165]", "v[104:107]") "v_rcp_f32 v102, v102"
+                     : "+{v[104:107]}"(acc3[1]), "+{v[100:103]}"(acc3[0])
+                     : "{v[150:153]}"(B3[2]), "{v[154:157]}"(B3[3]), "{v[158:161]}"(B3[4]), "{v[162:165]}"(B3[5]),
+                       [n00] "v"(A3[1][0][0]), [n10] "v"(A3[1][1][0]), [n01] "v"(A3[1][0][1]), [n11] "v"(A3[1][1][1]),
+                       [n02] "v"(A3[1][0][2]), [n12] "v"(A3[1][1][2]));
+        NTM2_STAMP(4)
+        // z chain, all three pieces (16 MFMAs); in its gaps the last v_rcp of the r sigmoid, then the n gate: p_n = r gh_n + gi_n,
+        // 4 x v_exp, + 1, 4 x v_rcp, n = 1 - 2 / (...); under the last MFMA's 28 cycles h - n; then the z sigmoid, the blend
+        // n + z (h - n) into the h registers, the hi pieces of h_t and their publication -- every wave's next step waits for it
+#define NTM3_S4(O_WH, SZC, GIC, GI0, GI1, GI2, GI3)                                                                                      \
+        asm volatile(MF3("v[108:111]", "%[z00]", "v[142:145]", SZC) "v_rcp_f32 v103, v103\n\t"                                      \
+                     MF3("v[108:111]", "%[z10]", "v[146:149]", "v[108:111]") FMA("v112", "v100", "v104", GI0) FMA("v113", "v101", "v105", GI1) \
+                     MF3("v[108:111]", "%[z01]", "v[142:145]", "v[108:111]") FMA("v114", "v102", "v106", GI2) FMA("v115", "v103", "v107", GI3) \
+                     MF3("v[108:111]", "%[z11]", "v[146:149]", "v[108:111]") "v_exp_f32 v112, v112\n\t"                            \
+                     MF3("v[108:111]", "%[z02]", "v[142:145]", "v[108:111]") "v_exp_f32 v113, v113\n\t"                            \
+                     MF3("v[108:111]", "%[z12]", "v[146:149]", "v[108:111]") "v_exp_f32 v114, v114\n\t"                            \
+                     MF3("v[108:111]", "%[z00]", "v[150:153]", "v[108:111]") "v_exp_f32 v115, v115\n\t"                            \
+                     MF3("v[108:111]", "%[z10]", "v[154:157]", "v[108:111]") "v_add_f32 v112, 1.0, v112\n\tv_add_f32 v113, 1.0, v113\n\t" \
+                     MF3("v[108:111]", "%[z01]", "v[150:153]", "v[108:111]") "v_add_f32 v114, 1.0, v114\n\tv_add_f32 v115, 1.0, v115\n\t" \
+                     MF3("v[108:111]", "%[z11]", "v[154:157]", "v[108:111]") "v_rcp_f32 v112, v112\n\t"                            \
+                     MF3("v[108:111]", "%[z02]", "v[150:153]", "v[108:111]") "v_rcp_f32 v113, v113\n\t"                            \
+                     MF3("v[108:111]", "%[z12]", "v[154:157]", "v[108:111]") "v_rcp_f32 v114, v114\n\t"                            \
+                     MF3("v[108:111]", "%[z00]", "v[158:161]", "v[108:111]") "v_rcp_f32 v115, v115\n\t"                            \
+                     MF3("v[108:111]", "%[z10]", "v[162:165]", "v[108:111]") FMA("v112", "v112", "-2.0", "1.0") FMA("v113", "v113", "-2.0", "1.0") \
+                     MF3("v[108:111]", "%[z01]", "v[158:161]", "v[108:111]") FMA("v114", "v114", "-2.0", "1.0") FMA("v115", "v115", "-2.0", "1.0") \
+                     MF3("v[108:111]", "%[z11]", "v[162:165]", "v[108:111]")                                                       \
+                     "v_sub_f32 v116, v124, v112\n\tv_sub_f32 v117, v125, v113\n\tv_sub_f32 v118, v126, v114\n\tv_sub_f32 v119, v127, v115\n\t" \
+                     "s_nop 1\n\t"                                                                                                \
+                     "v_exp_f32 v120, v108\n\tv_exp_f32 v121, v109\n\tv_exp_f32 v122, v110\n\tv_exp_f32 v123, v111\n\t"            \
+                     "v_pk_add_f32 v[120:121], v[120:121], 1.0 op_sel_hi:[1,0]\n\t"                                                \
+                     "v_pk_add_f32 v[122:123], v[122:123], 1.0 op_sel_hi:[1,0]\n\t"                                                \
+                     "v_rcp_f32 v120, v120\n\tv_rcp_f32 v121, v121\n\tv_rcp_f32 v122, v122\n\tv_rcp_f32 v123, v123\n\t"            \
+                     "v_pk_fma_f32 v[124:125], v[120:121], v[116:117], v[112:113]\n\t"                                             \
+                     "v_pk_fma_f32 v[126:127], v[122:123], v[118:119], v[114:115]\n\t"                                             \
+                     "v_cvt_pk_bf16_f32 v128, v124, v125\n\tv_cvt_pk_bf16_f32 v129, v126, v127\n\t"                                \
+                     "ds_write_b64 %[wr], v[128:129] offset:" O_WH                                                                \
+                     : "+{v[124:127]}"(h4), "=&{v[128:129]}"(p0v), "=&{v[108:111]}"(acc3[2]), "+{v[100:103]}"(acc3[0])              \
+                     : "{v[104:107]}"(acc3[1]), "{" SZC "}"(seed_z[cur]), "{" GIC "}"(gi4[cur]), [wr] "v"(wr_addr),                 \
+                       "{v[142:145]}"(B3[0]), "{v[146:149]}"(B3[1]),                                                              \
+                       "{v[150:153]}"(B3[2]), "{v[154:157]}"(B3[3]), "{v[158:161]}"(B3[4]), "{v[162:165]}"(B3[5]),                 \
+                       [z00] "v"(A3[2][0][0]), [z10] "v"(A3[2][1][0]), [z01] "v"(A3[2][0][1]), [z11] "v"(A3[2][1][1]),             \
+                       [z02] "v"(A3[2][0][2]), [z12] "v"(A3[2][1][2])                                                             \
+                     : "memory", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123")
+        if constexpr (cur == 0) NTM3_S4("6144", "v[170:173]", "v[174:177]", "v174", "v175", "v176", "v177");
+        else NTM3_S4("0", "v[210:213]", "v[206:209]", "v206", "v207", "v208", "v209");
+#undef NTM3_S4
+#undef FMA
+#undef NEG
+#undef MF3
+        NTM2_STAMP(5)
+        if constexpr (STAMP) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            seg[0] += ts_[0] - last_;
+#pragma unroll
+            for (int k = 1; k < 6; ++k) seg[k] += ts_[k] - ts_[k - 1];
+            last_ = ts_[5];
+        }
+#else
+        // ---- the compiler-scheduled form (NTM3_ASM = 0; libntm_bf16x3c.so of `make exp`): the same arithmetic, for the A/B
+        constexpr int cur = decltype(cur_c)::value;   // == t & 1: which exchange buffer holds h_{t-1}
+        const int ph = (int)(t & 63);
+        const int64_t tile = t >> 6;
+        // barrier 1: every wave's hi piece of h_{t-1} has landed (its own writes: all retired, lgkmcnt(0))
+        NTM2_STAMP(0)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        NTM2_STAMP(1)
+        const bf16x8 Bh0 = *(const bf16x8 *)(h3rd + cur * HB3);
+        const bf16x8 Bh1 = *(const bf16x8 *)(h3rd + cur * HB3 + 3 * 256);
+        // ---- in the shadow of that round trip: the mid and lo pieces of this wave's quarter, published; the head partial of
+        //      y_{t-1} (t = 0: h_0's, into a slot that sample 127 rewrites before any flush reads it); tile housekeeping
+        {
+            bf16x2 m_[2], l_[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const f32x2 r1 = hold[p] - __builtin_convertvector(h3hi[p], f32x2);
+                m_[p] = __builtin_convertvector(r1, bf16x2);
+                const f32x2 r2 = r1 - __builtin_convertvector(m_[p], f32x2);
+                l_[p] = __builtin_convertvector(r2, bf16x2);
+            }
+            *(bf16x4 *)(h3wr + cur * HB3 + 256) = (bf16x4){m_[0][0], m_[0][1], m_[1][0], m_[1][1]};
+            *(bf16x4 *)(h3wr + cur * HB3 + 512) = (bf16x4){l_[0][0], l_[0][1], l_[1][0], l_[1][1]};
+        }
+        park_head(t - 1);
+        housekeeping(t, ph, tile, hk_c);
+        NTM2_STAMP(2)
+
+        // ---- the 18 MFMAs on the hi pieces (W_1, W_2, W_3 . h_1); behind the first six: barrier 2 (every wave's mid / lo
+        //      pieces have landed), their reads and x of step t+1
+        f32x4 acc_r = {cr[0][0], cr[0][1], cr[1][0], cr[1][1]};
+        f32x4 acc_n = {bhn[0][0], bhn[0][1], bhn[1][0], bhn[1][1]};
+        f32x4 acc_z = {cz[0][0], cz[0][1], cz[1][0], cz[1][1]};
+        NTM3_MF(acc_r, 0, 0, 0, Bh0); NTM3_MF(acc_n, 1, 0, 0, Bh0); NTM3_MF(acc_z, 2, 0, 0, Bh0);
+        NTM3_MF(acc_r, 0, 1, 0, Bh1); NTM3_MF(acc_n, 1, 1, 0, Bh1); NTM3_MF(acc_z, 2, 1, 0, Bh1);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z)::"memory");
+        const bf16x8 Bm0 = *(const bf16x8 *)(h3rd + cur * HB3 + 1 * 256);
+        const bf16x8 Bm1 = *(const bf16x8 *)(h3rd + cur * HB3 + 4 * 256);
+        const bf16x8 Bl0 = *(const bf16x8 *)(h3rd + cur * HB3 + 2 * 256);
+        const bf16x8 Bl1 = *(const bf16x8 *)(h3rd + cur * HB3 + 5 * 256);
+        float xn = xb[(((t + 1) >> 6) & 1) * SG * XS + j * XS + (int)((t + 1) & 63)];
+#pragma unroll
+        for (int p = 1; p < 3; ++p) {
+            NTM3_MF(acc_r, 0, 0, p, Bh0); NTM3_MF(acc_n, 1, 0, p, Bh0); NTM3_MF(acc_z, 2, 0, p, Bh0);
+            NTM3_MF(acc_r, 0, 1, p, Bh1); NTM3_MF(acc_n, 1, 1, p, Bh1); NTM3_MF(acc_z, 2, 1, p, Bh1);
+        }
+        asm volatile("" : "+v"(acc_r), "+v"(acc_n), "+v"(acc_z), "+v"(xn));
+        NTM2_STAMP(3)
+
+        // ---- the 30 MFMAs on the mid and lo pieces, chain after chain; the vector pipe works in their gaps (one op per gap:
+        //      a bf16 MFMA holds the vector issue for 8 of its 16 cycles).  Each `asm` pins one gap: the MFMA and the vector op
+        //      in front of it are issued there, their consumers behind it.
+        // r chain; in its gaps the input terms of step t+1
+        const f32x2 xx = {xn, xn};
+        f32x2 ncr[2], ncz[2], ngi[2];
+        NTM3_MF(acc_r, 0, 0, 0, Bm0); NTM3_MF(acc_r, 0, 1, 0, Bm1);
+        NTM3_MF(acc_r, 0, 0, 1, Bm0); NTM3_MF(acc_r, 0, 1, 1, Bm1);
+        NTM3_MF(acc_r, 0, 0, 2, Bm0);
+        ncr[0] = __builtin_elementwise_fma(wir[0], xx, br[0]);
+        asm volatile("" : "+v"(acc_r), "+v"(ncr[0]));
+        NTM3_MF(acc_r, 0, 1, 2, Bm1);
+        ncr[1] = __builtin_elementwise_fma(wir[1], xx, br[1]);
+        asm volatile("" : "+v"(acc_r), "+v"(ncr[1]));
+        NTM3_MF(acc_r, 0, 0, 0, Bl0);
+        ncz[0] = __builtin_elementwise_fma(wiz[0], xx, bz[0]);
+        asm volatile("" : "+v"(acc_r), "+v"(ncz[0]));
+        NTM3_MF(acc_r, 0, 1, 0, Bl1);
+        ncz[1] = __builtin_elementwise_fma(wiz[1], xx, bz[1]);
+        asm volatile("" : "+v"(acc_r), "+v"(ncz[1]));
+        NTM3_MF(acc_r, 0, 0, 1, Bl0);
+        ngi[0] = __builtin_elementwise_fma(win[0], xx, bin_[0]);
+        asm volatile("" : "+v"(acc_r), "+v"(ngi[0]));
+        NTM3_MF(acc_r, 0, 1, 1, Bl1);
+        ngi[1] = __builtin_elementwise_fma(win[1], xx, bin_[1]);
+        asm volatile("" : "+v"(acc_r), "+v"(ngi[1]), "+v"(acc_n));
+        if (!PRESCALE) acc_r *= -LOG2E;
+        // n chain; in its gaps the r sigmoid: 4 x v_exp, 2 x v_pk_add, 4 x v_rcp
+        const f32x2 one = {1.0f, 1.0f};
+        float e0, e1, e2, e3;
+        NTM3_MF(acc_n, 1, 0, 0, Bm0); e0 = __builtin_amdgcn_exp2f(acc_r[0]); asm volatile("" : "+v"(acc_n), "+v"(e0), "+v"(acc_r));
+        NTM3_MF(acc_n, 1, 1, 0, Bm1); e1 = __builtin_amdgcn_exp2f(acc_r[1]); asm volatile("" : "+v"(acc_n), "+v"(e1), "+v"(acc_r));
+        NTM3_MF(acc_n, 1, 0, 1, Bm0); e2 = __builtin_amdgcn_exp2f(acc_r[2]); asm volatile("" : "+v"(acc_n), "+v"(e2), "+v"(acc_r));
+        NTM3_MF(acc_n, 1, 1, 1, Bm1); e3 = __builtin_amdgcn_exp2f(acc_r[3]); asm volatile("" : "+v"(acc_n), "+v"(e3));
+        f32x2 s01 = {e0, e1}, s23 = {e2, e3};
+        NTM3_MF(acc_n, 1, 0, 2, Bm0); s01 += one; asm volatile("" : "+v"(acc_n), "+v"(s01), "+v"(s23));
+        NTM3_MF(acc_n, 1, 1, 2, Bm1); s23 += one; asm volatile("" : "+v"(acc_n), "+v"(s23), "+v"(s01));
+        float r0, r1, r2, r3;
+        NTM3_MF(acc_n, 1, 0, 0, Bl0); r0 = __builtin_amdgcn_rcpf(s01[0]); asm volatile("" : "+v"(acc_n), "+v"(r0), "+v"(s01), "+v"(s23));
+        NTM3_MF(acc_n, 1, 1, 0, Bl1); r1 = __builtin_amdgcn_rcpf(s01[1]); asm volatile("" : "+v"(acc_n), "+v"(r1), "+v"(s23));
+        NTM3_MF(acc_n, 1, 0, 1, Bl0); r2 = __builtin_amdgcn_rcpf(s23[0]); asm volatile("" : "+v"(acc_n), "+v"(r2), "+v"(s23));
+        NTM3_MF(acc_n, 1, 1, 1, Bl1); r3 = __builtin_amdgcn_rcpf(s23[1]); asm volatile("" : "+v"(acc_n), "+v"(r3), "+v"(acc_z));
+        const f32x2 rr[2] = {{r0, r1}, {r2, r3}};
+        // z chain; in its gaps the n gate: tanh(gi_n + r gh_n) = 1 - 2 / (1 + 2^(2 log2e (...)))
+        f32x2 pn0, pn1;
+        NTM3_MF(acc_z, 2, 0, 0, Bm0);
+        pn0 = __builtin_elementwise_fma(rr[0], (f32x2){acc_n[0], acc_n[1]}, gi[0]);
+        pn1 = __builtin_elementwise_fma(rr[1], (f32x2){acc_n[2], acc_n[3]}, gi[1]);
+        if (!PRESCALE) { pn0 *= 2.0f * LOG2E; pn1 *= 2.0f * LOG2E; }
+        asm volatile("" : "+v"(acc_z), "+v"(pn0), "+v"(pn1));
+        float f0, f1, f2, f3;
+        NTM3_MF(acc_z, 2, 1, 0, Bm1); f0 = __builtin_amdgcn_exp2f(pn0[0]); asm volatile("" : "+v"(acc_z), "+v"(f0), "+v"(pn0), "+v"(pn1));
+        NTM3_MF(acc_z, 2, 0, 1, Bm0); f1 = __builtin_amdgcn_exp2f(pn0[1]); asm volatile("" : "+v"(acc_z), "+v"(f1), "+v"(pn1));
+        NTM3_MF(acc_z, 2, 1, 1, Bm1); f2 = __builtin_amdgcn_exp2f(pn1[0]); asm volatile("" : "+v"(acc_z), "+v"(f2), "+v"(pn1));
+        NTM3_MF(acc_z, 2, 0, 2, Bm0); f3 = __builtin_amdgcn_exp2f(pn1[1]); asm volatile("" : "+v"(acc_z), "+v"(f3));
+        f32x2 u01 = {f0, f1}, u23 = {f2, f3};
+        NTM3_MF(acc_z, 2, 1, 2, Bm1); u01 += one; u23 += one; asm volatile("" : "+v"(acc_z), "+v"(u01), "+v"(u23));
+        float g0, g1, g2, g3;
+        NTM3_MF(acc_z, 2, 0, 0, Bl0); g0 = __builtin_amdgcn_rcpf(u01[0]); asm volatile("" : "+v"(acc_z), "+v"(g0), "+v"(u01), "+v"(u23));
+        NTM3_MF(acc_z, 2, 1, 0, Bl1); g1 = __builtin_amdgcn_rcpf(u01[1]); asm volatile("" : "+v"(acc_z), "+v"(g1), "+v"(u23));
+        NTM3_MF(acc_z, 2, 0, 1, Bl0); g2 = __builtin_amdgcn_rcpf(u23[0]); asm volatile("" : "+v"(acc_z), "+v"(g2), "+v"(u23));
+        NTM3_MF(acc_z, 2, 1, 1, Bl1); g3 = __builtin_amdgcn_rcpf(u23[1]); asm volatile("" : "+v"(acc_z), "+v"(g3));
+        NTM2_STAMP(4)
+        // while the last MFMAs drain: n = 1 - 2 / (1 + 2^...), h - n
+        const f32x2 n0 = __builtin_elementwise_fma((f32x2){-2.0f, -2.0f}, (f32x2){g0, g1}, one);
+        const f32x2 n1 = __builtin_elementwise_fma((f32x2){-2.0f, -2.0f}, (f32x2){g2, g3}, one);
+        f32x2 d0 = hold[0] - n0, d1 = hold[1] - n1;
+        asm volatile("" : "+v"(d0), "+v"(d1), "+v"(acc_z));
+        // ---- the tail: z sigmoid, blend
+        if (!PRESCALE) acc_z *= -LOG2E;
+        f32x2 v01 = {__builtin_amdgcn_exp2f(acc_z[0]), __builtin_amdgcn_exp2f(acc_z[1])};
+        f32x2 v23 = {__builtin_amdgcn_exp2f(acc_z[2]), __builtin_amdgcn_exp2f(acc_z[3])};
+        v01 += one; v23 += one;
+        const f32x2 z0 = {__builtin_amdgcn_rcpf(v01[0]), __builtin_amdgcn_rcpf(v01[1])};
+        const f32x2 z1 = {__builtin_amdgcn_rcpf(v23[0]), __builtin_amdgcn_rcpf(v23[1])};
+        hold[0] = __builtin_elementwise_fma(z0, d0, n0);               // n + z (h - n)
+        hold[1] = __builtin_elementwise_fma(z1, d1, n1);
+        // publish the hi piece of h_t (on the critical path of every wave's next step); the rest follows behind barrier 1
+        h3hi[0] = __builtin_convertvector(hold[0], bf16x2);
+        h3hi[1] = __builtin_convertvector(hold[1], bf16x2);
+        *(bf16x4 *)(h3wr + (cur ^ 1) * HB3) = (bf16x4){h3hi[0][0], h3hi[0][1], h3hi[1][0], h3hi[1][1]};
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { cr[p] = ncr[p]; cz[p] = ncz[p]; gi[p] = ngi[p]; }
+        NTM2_STAMP(5)
+        if constexpr (STAMP) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            seg[0] += ts_[0] - last_;
+#pragma unroll
+            for (int k = 1; k < 6; ++k) seg[k] += ts_[k] - ts_[k - 1];
+            last_ = ts_[5];
+        }
+    #endif
+    };
+#undef NTM3_MF
     {
         using C0 = std::integral_constant<int, 0>;
         using C1 = std::integral_constant<int, 1>;
@@ -851,22 +1277,27 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         using HB = std::integral_constant<int, 2>;
         using HC = std::integral_constant<int, 3>;
         using HR = std::integral_constant<int, -1>;
+        // (always_inline: the step bodies must stay part of this kernel's one basic-block chain whatever the wrapper costs)
+        auto do_step = [&](const int64_t t, auto cur_c, auto hk_c) __attribute__((always_inline)) {
+            if constexpr (ENGINE == 2) step_b(t, cur_c, hk_c);
+            else step(t, cur_c, hk_c);
+        };
         const int64_t full = (T / TT) * TT;
         for (int64_t t0 = 0; t0 < full; t0 += TT) {          // whole tiles: housekeeping at compile-time positions
-            step(t0, C0{}, H0{}); step(t0 + 1, C1{}, H0{});
-            step(t0 + 2, C0{}, HA{}); step(t0 + 3, C1{}, H0{});
-            for (int p = 4; p < 34; p += 2) { step(t0 + p, C0{}, H0{}); step(t0 + p + 1, C1{}, H0{}); }
-            step(t0 + 34, C0{}, HB{}); step(t0 + 35, C1{}, H0{});
+            do_step(t0, C0{}, H0{}); do_step(t0 + 1, C1{}, H0{});
+            do_step(t0 + 2, C0{}, HA{}); do_step(t0 + 3, C1{}, H0{});
+            for (int p = 4; p < 34; p += 2) { do_step(t0 + p, C0{}, H0{}); do_step(t0 + p + 1, C1{}, H0{}); }
+            do_step(t0 + 34, C0{}, HB{}); do_step(t0 + 35, C1{}, H0{});
             if constexpr (FUSE) {
-                step(t0 + 36, C0{}, HC{}); step(t0 + 37, C1{}, H0{});
-                for (int p = 38; p < TT; p += 2) { step(t0 + p, C0{}, H0{}); step(t0 + p + 1, C1{}, H0{}); }
+                do_step(t0 + 36, C0{}, HC{}); do_step(t0 + 37, C1{}, H0{});
+                for (int p = 38; p < TT; p += 2) { do_step(t0 + p, C0{}, H0{}); do_step(t0 + p + 1, C1{}, H0{}); }
             } else {
-                for (int p = 36; p < TT; p += 2) { step(t0 + p, C0{}, H0{}); step(t0 + p + 1, C1{}, H0{}); }
+                for (int p = 36; p < TT; p += 2) { do_step(t0 + p, C0{}, H0{}); do_step(t0 + p + 1, C1{}, H0{}); }
             }
         }
         for (int64_t t = full; t < T; t += 2) {               // ragged last tile: phase tests at run time
-            step(t, C0{}, HR{});
-            if (t + 1 < T) step(t + 1, C1{}, HR{});
+            do_step(t, C0{}, HR{});
+            if (t + 1 < T) do_step(t + 1, C1{}, HR{});
         }
     }
     if constexpr (STAMP) {
@@ -875,6 +1306,13 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     }
 
     // ---- epilogue: remaining y tiles, final state ---------------------------------------------------
+    if constexpr (ENGINE == 2) {
+#if NTM3_ASM
+        hold[0] = (f32x2){h4[0], h4[1]};
+        hold[1] = (f32x2){h4[2], h4[3]};
+#endif
+        park_head(T - 1);      // (step_b parks the head partial of a sample one step later)
+    }
     __syncthreads();
     while (next_flush * TT < T) { flush_y_tile(next_flush, std::false_type{}); ++next_flush; }
     if constexpr (FUSE) {
@@ -969,11 +1407,15 @@ hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream)
         NTM2_ABL_CASE(3) NTM2_ABL_CASE(7) NTM2_ABL_CASE(18) NTM2_ABL_CASE(39) NTM2_ABL_CASE(55) NTM2_ABL_CASE(63)
         default: break;
     }
+    if (a.dbg && a.engine == 2) return NTM2_LAUNCH((gru_mfma2_kernel<true, true, 0, 2, 16>), m2::smem_floats(16, 2) * sizeof(float));
     if (a.dbg && a.tgt) return NTM2_LAUNCH((gru_mfma2_kernel<true, true, 0, 0, 16, false, true>), smem16);
     if (a.dbg) return NTM2_LAUNCH((gru_mfma2_kernel<true, true>), smem16);
 #else
     if (a.abl || a.dbg) return hipErrorInvalidValue;      // diagnostics live in libntm_lab.so
 #endif
+    constexpr size_t smem16b = m2::smem_floats(16, 2) * sizeof(float);   // ENGINE 2: 2 KB more exchange buffer
+    constexpr size_t smem4b = m2::smem_floats(4, 2) * sizeof(float);
+    static_assert(smem16b <= 160 * 1024, "LDS carve-up");
     if (a.tgt) {        // predict + ESR sums in one launch (exact fp32 engine)
         if (!a.esr_out || a.engine || (a.esr_skip & 3) || a.esr_skip < 0) return hipErrorInvalidValue;
         if (a.dcp_out)  // ... + the DCPreESR sums
@@ -982,6 +1424,9 @@ hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream)
         return many ? NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 4, false, true>), smem4)
                     : NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 0, 16, false, true>), smem16);
     }
+    if (a.engine == 2)
+        return many ? NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 2, 4>), smem4b)
+                    : NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 2, 16>), smem16b);
     if (a.engine == 1)
         return many ? NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 1, 4>), smem4)
                     : NTM2_LAUNCH((gru_mfma2_kernel<true, false, 0, 1, 16>), smem16);

@@ -63,6 +63,7 @@ int ntm_debug_gru_stamps(const float *w_ih, const float *w_hh, const float *b_ih
         a.esr_out = scratch;
         a.esr_skip = 0;
     }
+    if (variant == NTM_GRU_BF16X3) a.engine = 2;          // the stamped build of the bf16x3 step order
     hipError_t e = variant == NTM_GRU_MFMA ? ntm::launch_gru_mfma(a, (hipStream_t)stream)
                                            : ntm::launch_gru_mfma2(a, (hipStream_t)stream);
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_debug_gru_stamps");

@@ -33,7 +33,7 @@ struct GruArgs {
     int64_t B, T, xs, ys;
     unsigned long long *dbg;  // diagnostic stamp sums (ntm_debug_gru_stamps), else null
     int abl;                  // diagnostic ablation mask (ntm_debug_gru_ablate), else 0
-    int engine;               // MFMA2 GEMV engine: 0 exact fp32, 1 split-fp16 x3 (NTM_GRU_F16X3)
+    int engine;               // MFMA2 GEMV engine: 0 exact fp32, 1 split-fp16 x3 (NTM_GRU_F16X3), 2 split-bf16 x3 x3 (NTM_GRU_BF16X3)
     // fused DiffDelRNN step (gru_mfma2_kernel<FUSE>): `y` above is then pre_d, and the delay line writes yd
     const float *dd = nullptr;      // delay trajectory [B,T] in samples, contiguous
     float *yd = nullptr;            // delayed output [B,T], contiguous

@@ -20,7 +20,7 @@ __device__ float tcn_zeros[16 * 32];   // zero page (one row block) for rows bef
 
 #ifdef NTM_LAB
 // DIAGNOSTIC build (libntm_lab.so only, never timed as product): tcn_block_pg_kernel<false> takes s_memtime at six points
-// of every iteration and one wave leaves the per-segment sums here (ntm_lab_tcn_stamps, tools/tcn_stamp_probe.py).  The
+// of every iteration and one wave leaves the per-segment sums here (ntm_lab_tcn_stamps, tools/attic/tcn_stamp_probe.py).  The
 // wait sits inside the asm: s_memtime returns asynchronously and would otherwise land in a register pair the compiler
 // has already given to something else.
 __device__ unsigned long long tcn_stamp_out[8 + 3 * 64];   // [0..5] segment sums, [6] iterations, then per iteration: start, MFMA block, total

@@ -94,7 +94,7 @@ def read_wav_device(path, device="cuda"):
     """-> (float32 [C, N] tensor ON THE DEVICE, fs), the same values as read_wav.  The decode IS the host-to-device copy:
     the file is memory-mapped, its interleaved frames go through two pinned 64 MB staging buffers (the one host pass: page
     cache -> pinned) and over PCIe as they are, and the de-interleave, the conversion to fp32 and the PCM scaling run on the
-    device -- a 450 MB stereo float32 file takes 14 ms (tools/decode_probe.py) where wavfile.read + the numpy transpose +
+    device -- a 450 MB stereo float32 file takes 14 ms (tools/attic/decode_probe.py) where wavfile.read + the numpy transpose +
     pinning took 115 on the host.  With 288 GB of HBM a whole evaluation set lives on the device; SegmentFeeder falls back
     to the pinned-host layout when it does not fit."""
     dev = torch.device(device)

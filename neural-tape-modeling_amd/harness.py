@@ -79,7 +79,7 @@ def apply_delay(delay, delay_trajectory, output, segment_length=None):
 class BlockStreamer:
     """Block-by-block (real-time style) inference: B streams advance `block` samples per call with the GRU state kept
     on the device in preallocated buffers; one ctypes call per block on the low-latency kernel.  Measured on the
-    MI355X (tools/block_latency_probe.py): 20 us per 64-sample block of one stream (16 us of it kernel; the block
+    MI355X (tools/attic/block_latency_probe.py): 20 us per 64-sample block of one stream (16 us of it kernel; the block
     lasts 1451 us at 44.1 kHz), 36 us for 16 streams x 128 samples, 132 us for 256 x 512 -- i.e. about 5 us of
     launch overhead.  Capturing the launch in a HIP graph and replaying it (`use_graph=True`, torch.cuda.CUDAGraph)
     was measured too and is SLOWER by 8 us per block: with a single kernel per block there is nothing for a graph to

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5
 W_G = "GRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE]_BEST"
 W_D = "DiffDelGRU-HS[64]-L[DCPreESR]-DS[ReelToReel_Dataset_MiniPulse100_CHOWTAPE_WOWFLUTTER]_BEST"
-VARIANTS = ["mfma2", "mfma", "valu", "f16x3", "mfma3", "lat", "mfma4"]
+VARIANTS = ["mfma2", "mfma", "valu", "f16x3", "mfma3", "lat", "mfma4", "bf16x3"]
 
 
 @pytest.fixture(scope="module")
@@ -137,7 +137,7 @@ def test_ragged_shapes_vs_oracle(ntm, variant, B, T):
     assert np.abs(m.hidden.cpu().numpy()[0] - ho).max() < TOL
 
 
-@pytest.mark.parametrize("variant", ["mfma2", "f16x3"])
+@pytest.mark.parametrize("variant", ["mfma2", "f16x3", "bf16x3"])
 def test_many_groups_variant(ntm, variant):
     """B >= 8192 selects the small-LDS build of the MFMA2 kernel (several workgroups per CU, head partial
     pre-reduced with permlane swaps): check it against the oracle and against the one-per-CU build."""
@@ -165,7 +165,7 @@ def test_variants_agree_and_raw_abi_strides(ntm):
     xh = rng.uniform(-0.5, 0.5, (B, XS)).astype(np.float32)
     x = dev(xh)
     outs = []
-    for name in ("mfma2", "lat", "f16x3", "mfma", "valu", "mfma3", "mfma4"):
+    for name in ("mfma2", "lat", "f16x3", "mfma", "valu", "mfma3", "mfma4", "bf16x3"):
         y = torch.full((B, YS), 7.0, device="cuda")
         fn = LAB.ntm_lab_gru_forward if name in ntm._lib.LAB_VARIANTS else L.ntm_gru_forward_ex
         rc = fn(*[ctypes.c_void_p(sd[k].data_ptr()) for k in

@@ -33,7 +33,7 @@ pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
 TILE_B = 1040                    # > 1024 streams: "auto" takes the matrix-pipe kernel / the fused DiffDel step
-LOG = os.path.join(ROOT, "gpurun_out", "r05_checkpoint_parity.jsonl")
+LOG = os.path.join(ROOT, "gpurun_out", "r06_checkpoint_parity.jsonl")
 
 
 @pytest.fixture(scope="module")
@@ -66,18 +66,21 @@ def bar(y, ref32, y64, gate_noise, what):
     return d32, d64, own
 
 
-def opt_in_engine(m, x, ref32, y64, own, exact_d64, what):
-    """Round 5: the opt-in f16x3 engine (NTM_GRU_F16X3: W.h as three fp16 hi/lo products, the 2^-22 lo.lo term dropped --
-    NARROWER than fp32, never the headline) through the same goldens as the exact engine.  Recorded: |hip - ref32| and
-    |hip - f64| beside the exact engine's.  Asserted: it is no further from the float64 truth than the exact-fp32 engine is
-    allowed to be -- inside 1e-5 of the reference, or inside the checkpoint's own allowance, or within a factor 4 of what
-    the exact engine measures on the same golden (the sensitive checkpoints amplify ANY rounding change alike)."""
-    m.kernel_variant = "f16x3"
+def opt_in_engine(m, x, ref32, y64, own, exact_d64, what, engine="f16x3"):
+    """The opt-in split engines through the same goldens as the exact engine: f16x3 (NTM_GRU_F16X3: W.h as three fp16 hi/lo
+    products, the 2^-22 lo.lo term dropped -- NARROWER than fp32, never the headline) and, round 6, bf16x3 (NTM_GRU_BF16X3: W and h
+    as three bf16 pieces each, i.e. the fp32 operands exactly, eight of the nine partial products -- operand-exact).  Recorded:
+    |hip - ref32| and |hip - f64| beside the exact engine's.  Asserted: no further from the float64 truth than the exact-fp32
+    engine is allowed to be -- inside 1e-5 of the reference, or inside the checkpoint's own allowance, or within a factor 4
+    (f16x3) / 2 (bf16x3) of what the exact engine measures on the same golden (the sensitive checkpoints amplify ANY rounding
+    change alike)."""
+    m.kernel_variant = engine
     yb = m.predict(tile(x)).cpu().numpy()[ROWS, 0]
     m.kernel_variant = "auto"
     assert np.array_equal(yb[0], yb[1]) and np.array_equal(yb[0], yb[2])
     d32, d64 = float(np.abs(yb[0] - ref32).max()), float(np.abs(yb[0] - y64).max())
-    assert d32 < TOL or d64 <= max(own, 4.0 * exact_d64), f"{what} f16x3: |hip - ref32| = {d32:.2e}, |hip - f64| = {d64:.2e} (exact engine {exact_d64:.2e}, allowance {own:.2e})"
+    slack = 4.0 if engine == "f16x3" else 2.0
+    assert d32 < TOL or d64 <= max(own, slack * exact_d64), f"{what} {engine}: |hip - ref32| = {d32:.2e}, |hip - f64| = {d64:.2e} (exact engine {exact_d64:.2e}, allowance {own:.2e})"
     return d32, d64
 
 
@@ -124,6 +127,7 @@ def test_g19_every_shipped_checkpoint(ntm, name):
             assert np.array_equal(yb[0], yb[1]) and np.array_equal(yb[0], yb[2])         # same input -> same bits in every stream
             row[f"{variant}_d32"], row[f"{variant}_d64"], _ = bar(yb[0], ref, y64, gn, f"predict B={TILE_B} {variant}")
         row["f16x3_d32"], row["f16x3_d64"] = opt_in_engine(m, x, ref, y64, row["own"], row["auto_d64"], f"{name} predict B={TILE_B}")
+        row["bf16x3_d32"], row["bf16x3_d64"] = opt_in_engine(m, x, ref, y64, row["own"], row["auto_d64"], f"{name} predict B={TILE_B}", "bf16x3")
         # teacher-forced: forward() from the reference's own warm state
         m.kernel_variant = "auto"
         for B in (1, TILE_B):
@@ -200,6 +204,7 @@ def test_g20_gru_ten_second_segment(ntm, tag):
         assert np.array_equal(yb[0], yb[1]) and np.array_equal(yb[0], yb[2])
         row[f"{variant}_d32"], row[f"{variant}_d64"], _ = bar(yb[0], ref, y64, gn, f"B={TILE_B} {variant}")
     row["f16x3_d32"], row["f16x3_d64"] = opt_in_engine(m, x, ref, y64, row["own"], row["auto_d64"], f"{name} 441000 samples B={TILE_B}")
+    row["bf16x3_d32"], row["bf16x3_d64"] = opt_in_engine(m, x, ref, y64, row["own"], row["auto_d64"], f"{name} 441000 samples B={TILE_B}", "bf16x3")
     # forward + ESR sums in the same launch on the ragged length, against the reference's output as the target
     m.kernel_variant = "auto"
     tgt = tile(ref)

@@ -504,6 +504,12 @@ def test_full_size_cfg2_every_stream_against_the_oracle(ntm):
     m = ntm.harness.build_model(W_G)
     y = m.predict(x).cpu().numpy()[:, 0]
     h = m.hidden[0].cpu().numpy()
+    # the opt-in split engines on the same batch (round 6: the table the bf16x3 engine is judged by)
+    y_eng = {}
+    for eng in ("f16x3", "bf16x3"):
+        m.kernel_variant = eng
+        y_eng[eng] = m.predict(x).cpu().numpy()[:, 0]
+    m.kernel_variant = "auto"
     xs = x[:, 0].cpu().numpy()
     del x
     t0 = time.perf_counter()
@@ -514,6 +520,16 @@ def test_full_size_cfg2_every_stream_against_the_oracle(ntm):
     dt64 = time.perf_counter() - t0
     per = np.abs(y - yo).max(axis=1)
     mg = _margin(y, yo, y64)
+    for eng, ye in y_eng.items():
+        pe = np.abs(ye - yo).max(axis=1)
+        me = _margin(ye, yo, y64)
+        dh, de = np.abs(y - y64).max(axis=1), np.abs(ye - y64).max(axis=1)
+        _record_full(f"configs[1] GRU-HS[64] 4096 x 65536, engine {eng}", streams=B, worst=float(pe.max()), median=float(np.median(pe)),
+                     p99=float(np.quantile(pe, 0.99)), margin_y=me, exact_engine_hip_vs_f64=mg["hip_vs_f64"],
+                     streams_closer_to_f64_than_the_exact_engine=int((de <= dh).sum()),
+                     ratio_to_exact_engine_per_stream={"worst": float((de / np.maximum(dh, 1e-12)).max()), "median": float(np.median(de / np.maximum(dh, 1e-12)))})
+        assert pe.max() < TOL and me["hip_vs_f64"]["worst"] < TOL, (eng, pe.max())
+    del y_eng
     _record_full("configs[1] GRU-HS[64] 4096 x 65536", streams=B, worst=float(per.max()), worst_stream=int(per.argmax()), median=float(np.median(per)),
                  p99=float(np.quantile(per, 0.99)), state_worst=float(np.abs(h - ho).max()), margin_y=mg,
                  state_hip_vs_f64=float(np.abs(h - h64).max()), state_oracle32_vs_f64=float(np.abs(ho - h64).max()),
@@ -541,6 +557,10 @@ def test_full_size_cfg3_every_stream_against_the_oracle(ntm):
     y, pre = m.predict(x, d)
     y, pre = y.cpu().numpy()[:, 0], pre.cpu().numpy()[:, 0]
     h, buf = m.hidden[0].cpu().numpy(), m.diffdel.buffer[:, 0].cpu().numpy()
+    m.kernel_variant = "bf16x3"          # round 6: the split engine under the delay line (GRU launch + streaming delay pass)
+    yb, pb = m.predict(x, d)
+    yb, pb = yb.cpu().numpy()[:, 0], pb.cpu().numpy()[:, 0]
+    m.kernel_variant = "auto"
     xs, ds = x[:, 0].cpu().numpy(), d[:, 0].cpu().numpy()
     del x, d
     t0 = time.perf_counter()
@@ -551,7 +571,12 @@ def test_full_size_cfg3_every_stream_against_the_oracle(ntm):
     y64, p64, _, _ = oracle.diffdel_predict_f64(oracle_weights(W_D), xs, ds, m.max_delay, threads=threads)
     dt64 = time.perf_counter() - t0
     mp = _margin(pre, preo, p64)
-    del p64, preo
+    mpb, myb = _margin(pb, preo, p64), _margin(yb, yo, y64)
+    _record_full("configs[2] DiffDelGRU-HS[64] 4096 x 65536, D = 1847, engine bf16x3 (GRU launch + delay pass)", streams=B,
+                 worst_y=float(np.abs(yb - yo).max()), worst_pre_d=float(np.abs(pb - preo).max()), margin_pre_d=mpb, margin_y=myb,
+                 exact_engine_hip_vs_f64=mp["hip_vs_f64"])
+    assert np.abs(yb - yo).max() < TOL and np.abs(pb - preo).max() < TOL and mpb["hip_vs_f64"]["worst"] < TOL
+    del p64, preo, pb, yb
     my = _margin(y, yo, y64)
     _record_full("configs[2] DiffDelGRU-HS[64] 4096 x 65536, D = 1847 (fused step)", streams=B, worst_y=float(per_y.max()), worst_pre_d=float(per_p.max()),
                  worst_stream=int(per_p.argmax()), median_pre_d=float(np.median(per_p)), p99_pre_d=float(np.quantile(per_p, 0.99)),

@@ -34,7 +34,7 @@ def test_cabi_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lab, s), f"libntm_lab.so does not export {s}"
         assert not hasattr(lib, s), f"the product library exports the laboratory symbol {s}"
     assert set(ntm_amd._lib._LAB_SIGNATURES) == set(lab_syms)
-    assert ntm_amd._lib.lib().ntm_abi_version() == 8 == ntm_amd._lib.ABI_VERSION
+    assert ntm_amd._lib.lib().ntm_abi_version() == 9 == ntm_amd._lib.ABI_VERSION
 
 
 def test_rccl_helper_library_loads_and_exports_its_header():
@@ -279,6 +279,14 @@ def test_recorded_bench_line_follows_the_contract():
         assert v["value"] > 0 and (k == "cli" or (0.3 < v["frac"] < 1.0 and v["vs_oracle_max_abs"] < 1e-5)), k
     # round 6: the two stale traffic figures re-measured with this round's binary -- every leg states PMC bytes over algorithmic bytes
     assert 1.0 <= c["legs"]["diffdel"]["traffic_ratio"] < 1.4 and c["legs"]["tcn"]["traffic_ratio"] > 50
+    # round 6: the opt-in split engines ride beside `value` (never in it): kernel time and whole-batch distance from the exact pass;
+    # the detail file prices the bf16x3 engine both ways (executed bf16 MFMA flops / bf16 peak, algorithmic flops / fp32 peak)
+    e = c["opt_in_engines"]
+    assert 20 < e["f16x3"]["kernel_ms"] < e["bf16x3"]["kernel_ms"] < rc["kernel_ms"] and e["bf16x3"]["vs_exact_fp32_max_abs"] < 1e-5
+    b3 = d["other_kernels"]["bf16x3"]
+    assert abs(b3["roofline_executed"]["frac"] - 196608.0 * 4096 * 65536 / (b3["kernel_ms"] * 1e-3) / 2.5e15) < 1e-9
+    assert abs(b3["roofline_algorithmic"]["frac"] - 25088.0 * 4096 * 65536 / (b3["kernel_ms"] * 1e-3) / 157.3e12) < 1e-9
+    assert b3["speedup_vs_exact_fp32_kernel"] > 1.3 and b3["stream0_vs_reference_max_abs"] < 1e-5
     assert c["build"]["hip"] and c["build"]["runtime_hip"] and len(c["build"]["library_sha256"]) == 16
     assert d["build"]["library_sha256"].startswith(c["build"]["library_sha256"])
     assert d["unit"] == "samples/s" and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"

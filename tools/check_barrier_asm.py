@@ -32,7 +32,7 @@ LGKM = re.compile(r"^\s*(ds_|s_load_|s_buffer_load|s_memtime|s_memrealtime|s_sen
 
 # `s_waitcnt vmcnt(0)` in the hot loop (10 unrolled steps) of the binary the round-3/4 profiles were taken from (ROCm 7.2 hipcc),
 # keyed by the template arguments (ENGINE, FUSE, ESR); the same for YPN = 4 and 16
-MAX_DRAINS = {(0, 0, 0): 3, (0, 0, 1): 6, (1, 0, 0): 3, (0, 1, 0): 4, (0, 1, 1): 6}
+MAX_DRAINS = {(0, 0, 0): 3, (0, 0, 1): 6, (1, 0, 0): 3, (0, 1, 0): 4, (0, 1, 1): 6, (2, 0, 0): 3}
 MAX_DRAINS_DCP = 5            # ESR + DCP (the DCPreESR sums in the same flush): as the ESR instantiation
 
 
@@ -81,6 +81,24 @@ def check(defines=()):
                                   f"{pinned}: hipcc's wait insertion changed (DESIGN.md 4 K2f) -- re-measure")
         if drains < pinned:
             print(f"note: {name}: {drains} drains in the hot loop (pinned {pinned})")
+        if key[0] == 2:
+            # bf16x3 engine (step_b): no hand-counted wait -- every barrier of the step follows an `s_waitcnt lgkmcnt(0)` with no
+            # LDS / SMEM operation in between (barrier 1 directly; barrier 2 with one MFMA between), inside the asm statements
+            # or, in the compiler-scheduled form, in front of them
+            lines = [t for t in (ln.split(";")[0].strip() for ln in body.splitlines()) if t]
+            n2 = 0
+            for i, t in enumerate(lines):
+                if t != "s_barrier":
+                    continue
+                k = i - 1
+                while k >= 0 and not (lines[k].startswith("s_waitcnt") and "lgkmcnt(0)" in lines[k]):
+                    assert not LGKM.match(lines[k]), f"{name}: {lines[k]!r} between the full wait and a barrier of the bf16x3 step"
+                    assert i - k < 6, f"{name}: a barrier of the bf16x3 step without `s_waitcnt lgkmcnt(0)` in front"
+                    k -= 1
+                n2 += 1
+            assert n2 >= 4, f"{name}: only {n2} barriers found"
+            checked += n2
+            continue
         # Instructions in layout order, labels and branches kept as block boundaries.  The step is inlined several times
         # (compile-time housekeeping positions), inside loops and in straight-line runs, so the invariant is checked as
         # two local properties that compose over every path from one step copy to the next:

@@ -32,8 +32,10 @@ PINNED_VGPRS = {
     (0, 16, 1, 1, 0): 234, (0, 4, 1, 1, 0): 228,
     (0, 16, 0, 1, 1): 264, (0, 4, 0, 1, 1): 220,          # ESR + DCP: 256 VGPRs + 8 AGPRs (AGPR spills, no scratch)
     (0, 16, 1, 1, 1): 251, (0, 4, 1, 1, 1): 243,          # FUSE + ESR + DCP
+    (2, 16, 0, 0, 0): 263, (2, 4, 0, 0, 0): 263,          # bf16x3 engine (round 6; opt-in): 256 VGPRs + 7 AGPRs outside the loop
 }
 MFMA2_DYNAMIC_LDS = {16: 151680, 4: 53376}      # csrc/gru_mfma2.hip m2::smem_floats(YPN) * 4
+MFMA2_DYNAMIC_LDS_BF16X3 = {16: 153728, 4: 55424}      # ... m2::smem_floats(YPN, 2) * 4: the exchange buffer holds three pieces
 
 
 def hipcc_version():
@@ -96,7 +98,7 @@ def build_info(lib_path=DEFAULT_LIB):
     for k in ks:
         key = mfma2_key(k["symbol"])
         if key:
-            k["lds_dynamic_bytes"] = MFMA2_DYNAMIC_LDS.get(key[1])
+            k["lds_dynamic_bytes"] = (MFMA2_DYNAMIC_LDS_BF16X3 if key[0] == 2 else MFMA2_DYNAMIC_LDS).get(key[1])
             k["pinned_vgprs"] = PINNED_VGPRS.get(key)
     try:
         src = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=30).stdout.strip() or None

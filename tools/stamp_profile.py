@@ -15,8 +15,9 @@ g, o = m.GRU, m.output
 L = ntm_amd._lib.lib()
 LAB = ntm_amd._lib.lab()          # stamps / ablations: diagnostic builds in libntm_lab.so
 NAMES = {1: ["lds_read", "phaseA", "phaseB", "tail", "lds_write", "barrier"],
-         3: ["mfma1-3(+bookkeeping)", "wait_own_wr", "barrier", "rd+45mfma", "hk+cinit+gates", "wr+head"]}
-for variant in (3, 1):
+         3: ["mfma1-3(+bookkeeping)", "wait_own_wr", "barrier", "rd+45mfma", "hk+cinit+gates", "wr+head"],
+         8: ["between_steps", "hk+x_read", "bar1+rd_hi+split+12mfma", "6mfma(z hi)+head", "20mfma(r,n rest)+seeds+r_sigm", "10mfma+n_gate+z_sigm+publish"]}
+for variant in [int(v) for v in os.environ.get('NTM_STAMP_VARIANTS', '3,1,8').split(',')]:
     for _ in range(2):
         rc = LAB.ntm_debug_gru_stamps(ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0),
                                     ptr(o.weight), ptr(o.bias), ptr(x), ptr(y), B, T, ptr(h), ptr(st), variant, None)
@@ -28,7 +29,7 @@ for variant in (3, 1):
         print(f"  wave {w}: " + "  ".join(f"{n}={s[:, w, k].mean():7.1f}" for k, n in enumerate(NAMES[variant]))
               + f"  total={s[:, w, :].sum(1).mean():7.1f}")
     if variant == 3:
-        h = st.cpu().numpy().astype(np.float64)[:, :, 6:] / (T // 64)
+        hk = st.cpu().numpy().astype(np.float64)[:, :, 6:] / (T // 64)
         print("  the phase-2 step of a tile alone (x-tile fetch, y-tile flush), cycles per occurrence:")
         for w in range(4):
-            print(f"  wave {w}: " + "  ".join(f"{n}={h[:, w, k].mean():7.1f}" for k, n in enumerate(NAMES[3])) + f"  total={h[:, w, :].sum(1).mean():7.1f}")
+            print(f"  wave {w}: " + "  ".join(f"{n}={hk[:, w, k].mean():7.1f}" for k, n in enumerate(NAMES[3])) + f"  total={hk[:, w, :].sum(1).mean():7.1f}")
