@@ -263,7 +263,7 @@ def measure_workload(workload, B, T, steps, warmup, check, dev, threads=1, delay
             # the streaming delay pass: 12 more bytes per sample) is timed beside it for the A/B.
             roof["kernel"] = kernel = "gru_mfma2_kernel<FUSE: GRU + head + delay line> (+ delay_update_kernel)"
             roof["hbm_bytes_per_sample"] = 16
-            if T == 65536:                       # PMC traffic of the fused kernel (~1.25 x the algorithmic bytes,
+            if T == 65536:                       # PMC traffic of the fused kernel (measurement log 4 K2f: ~1.25 x the algorithmic bytes,
                 import glob                      # the taps come back from beyond L2)
                 why = None
                 ypn = 4 if (B + 15) // 16 > torch.cuda.get_device_properties(dev).multi_processor_count else 16      # launch_gru_mfma2

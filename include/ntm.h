@@ -43,7 +43,7 @@ extern "C" {
                          streams the weights from L2 (correct, not fast).                                          */
 #define NTM_MAX_HIDDEN 1024
 
-/* GRU kernel variants.  ntm_gru_forward_ex of libntm.so (the product) accepts NTM_GRU_AUTO, _MFMA2,
+/* GRU kernel variants (the laboratory ones: docs/DESIGN_measurement_log_r1_r5.md).  ntm_gru_forward_ex of libntm.so (the product) accepts NTM_GRU_AUTO, _MFMA2,
  * _LAT and the opt-in _F16X3 / _BF16X3; the others are LABORATORY kernels -- older or experimental exact-fp32 implementations
  * kept as independent checks and as measured dead ends -- compiled into libntm_lab.so only (include/ntm_lab.h).  */
 #define NTM_GRU_AUTO 0  /* NTM_GRU_MFMA2, or NTM_GRU_LAT when B <= NTM_GRU_LAT_MAX_B         */

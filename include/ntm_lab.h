@@ -2,7 +2,7 @@
  * ntm_lab.h -- C ABI of libntm_lab.so: the LABORATORY beside the product library libntm.so (include/ntm.h).
  *
  * Older and experimental exact-fp32 GRU-HS[64] kernels (kept as independent implementations for the parity tests and
- * as documented, measured dead ends: DESIGN.md) and the diagnostic builds of the product kernel.  Nothing on the
+ * as documented, measured dead ends: docs/DESIGN_measurement_log_r1_r5.md) and the diagnostic builds of the product kernel.  Nothing on the
  * product path loads this library; same pointer / stream / error conventions as ntm.h.
  */
 #ifndef NTM_LAB_H

@@ -1,4 +1,4 @@
-// GRU-HS[64] + affine head, persistent over the whole sequence (K1 in DESIGN.md).
+// GRU-HS[64] + affine head, persistent over the whole sequence (K1 in docs/DESIGN_measurement_log_r1_r5.md).
 //
 // Replaces torch.nn.GRU(1,64,batch_first=True) + torch.nn.Linear(64,1) as the reference calls them
 // at code/model.py:81-82 / :412-413.  Per sample and stream (gate row order r,z,n):

@@ -145,7 +145,7 @@ __device__ __forceinline__ f32x4 pack_hl(const f16x4 hi, const f16x4 lo)
 //   bits each) and W.h is evaluated as Wh.hh + Wh.hl + Wl.hh on v_mfma_f32_16x16x16_f16 with fp32
 //   accumulation (products of fp16 pairs are exact in fp32; the dropped Wl.hl term is ~2^-22 relative).
 //   Everything outside the GEMV (state, gates, head) stays fp32.  Measured error vs the reference is
-//   the same as ENGINE 0's.  Per step and wave 27 MFMAs of ~17 cycles instead of 48 x 32:
+//   the same as ENGINE 0's (docs/DESIGN_measurement_log_r1_r5.md, "f16x3 on every golden").  Per step and wave 27 MFMAs of ~17 cycles instead of 48 x 32:
 //   own quarter 9 x K16, the two other quarters that are adjacent in the exchange row as 9 x K32
 //   (v_mfma_f32_16x16x32_f16), the remaining quarter 9 x K16.
 // ENGINE 2: "bf16x3" -- W and h are each split into THREE bf16 pieces (24 significant bits: the fp32 operands exactly, over
@@ -165,7 +165,7 @@ __device__ __forceinline__ f32x4 pack_hl(const f16x4 hi, const f16x4 lo)
 //   CU -- right for B <= 4096 where a CU has a single 16-stream group anyway).
 // YPN = 4: the four lane groups of a wave are summed first (two permlane swaps), 4 planes, 53 KB of LDS:
 //   two or three workgroups share a CU and one group's MFMAs overlap another group's gate math
-//   (overlap only exists across waves) -- used when B >= 8192.
+//   (overlap only exists across waves, docs/DESIGN_measurement_log_r1_r5.md §4) -- used when B >= 8192.
 // FUSE = true: the DiffDelRNN step (code/model.py:393-424) in ONE launch.  `a.y` is then pre_d (the GRU + bias-free head)
 //   and the time-varying delay line (code/model.py:269-320) writes a.yd from it inside the y-tile housekeeping, one
 //   64-sample tile behind the recurrence and spread over three compile-time positions of a tile so that no load
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 #if NTM2_HKTRIM
     // The same loads for a tile that lies entirely inside [0, T): no bound on the sample index, row pointers computed
     // once (an absent stream reads the workgroup's first row: its column of the batch is never stored).  At one wave per
-    // SIMD every instruction of a housekeeping step costs the recurrence ~4.5 cycles, a taken branch ~20.
+    // SIMD every instruction of a housekeeping step costs the recurrence ~4.5 cycles, a taken branch ~20 (measurement log 4 K2f).
     const float *xrow[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     (void)esr_e; (void)esr_t; (void)esr_tg; (void)esr_tile; (void)esr_row;
     // ONE unconditional 16-byte load into esr_tg on the common path; the general form (first flush of a launch, ragged
     // tail) fetches into registers of its own -- a second, conditional load path into the SAME registers makes hipcc drain
-    // the VM counter in front of the common one
+    // the VM counter in front of the common one (measurement log 4 K2f)
     auto esr_fetch_whole = [&](int64_t tile) {
         esr_tg = *(const f32x4y *)(esr_row + tile * TT);
         esr_tile = tile;

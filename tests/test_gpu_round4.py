@@ -18,7 +18,7 @@ The bar, per golden:
     (2) predict():  |hip - ref32| < 1e-5;  where the checkpoint's own measures exceed 1e-5 -- max(2 |ref32 - y64|, gate noise)
         -- the result must instead be as close to the float64 truth as those measures: |hip - y64| <= max(2 |ref32 - y64|,
         gate_noise.max()).  For the other 28 checkpoints (2) IS the plain 1e-5.
-Every number lands in gpurun_out/r04_checkpoint_parity.jsonl (copied to profiles/ and tabulated in DESIGN.md).
+Every number lands in gpurun_out/r06_checkpoint_parity.jsonl (copied to profiles/; summarised in DESIGN.md 2 and 4).
 """
 import json
 import os

@@ -8,7 +8,7 @@ disassembly of every non-diagnostic instantiation is checked here: walking back 
 h-exchange write (ds_write_b128, or the two ds_write_b64 of the f16x3 engine) there must be exactly one lgkm-counted
 instruction and it must be a ds_write_b32.
 
-Second check (round 4): full drains of the vector-memory counter in the hot loop.  DESIGN.md 4 K2f lists two behaviours of
+Second check (round 4): full drains of the vector-memory counter in the hot loop.  docs/DESIGN_measurement_log_r1_r5.md 4 K2f lists two behaviours of
 hipcc's wait insertion that each exposed a memory round trip per 64-sample tile (a `s_waitcnt vmcnt(0)` in front of a load that
 did not need it: 1 % of the step, silently); the kernel steers around them with __builtin_amdgcn_s_waitcnt at run-time-free
 places.  Whether that still works is a property of the compiler, so the number of `s_waitcnt vmcnt(0)` inside the
@@ -78,7 +78,7 @@ def check(defines=()):
         assert key in MAX_DRAINS, f"{name}: instantiation {key} has no pinned drain count"
         pinned = MAX_DRAINS_DCP if flags[2] else MAX_DRAINS[key]
         assert drains <= pinned, (f"{name}: {drains} x `s_waitcnt vmcnt(0)` in the hot loop, the measured binary has "
-                                  f"{pinned}: hipcc's wait insertion changed (DESIGN.md 4 K2f) -- re-measure")
+                                  f"{pinned}: hipcc's wait insertion changed (measurement log 4 K2f) -- re-measure")
         if drains < pinned:
             print(f"note: {name}: {drains} drains in the hot loop (pinned {pinned})")
         if key[0] == 2:

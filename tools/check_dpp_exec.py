@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build-time check for a hipcc behaviour that cost a silent wrong result in round 5: a DPP move written under a
+"""Build-time check for a hipcc behaviour that cost a silent wrong result in round 5 (docs/DESIGN_measurement_log_r1_r5.md 13): a DPP move written under a
 select (`lane ? dpp(x) : y`) was SUNK into the divergent branch, where lanes read from EXEC-disabled neighbours and get nothing.
 Cross-lane DPP operations (row_shr / row_bcast / row_newbcast / quad_perm / wave_shr ...) in the product kernels are all meant to run
 with the full wavefront active; this script disassembles the kernels that use them and proves, by a forward data-flow over the

@@ -8,7 +8,7 @@ it to its line as `build`, so a compiler change or a box-to-box difference shows
 
 --check (also run by tests/test_host.py): no PRODUCT kernel may use scratch or spill a register, and the recurrent
 kernels' VGPR counts may not exceed the binary the committed profiles were measured on (PINNED_VGPRS below) -- the kernel
-leans on hipcc-specific workarounds, so a silent register-allocation change is a performance event."""
+leans on hipcc-specific workarounds (docs/DESIGN_measurement_log_r1_r5.md 4), so a silent register-allocation change is a performance event."""
 import json
 import os
 import re
