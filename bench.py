@@ -1071,6 +1071,27 @@ def main():
         if gold is not None:
             extra["bf16x3"]["stream0_vs_reference_max_abs"] = float(np.abs(gold["y"][0, 0] - y4[0, 0].cpu().numpy()).max())
         del y4
+        if (B, T) == (4096, 65536):
+            # from 8192 streams up two stream groups share a CU (250 registers: two waves per SIMD) and one group's LDS exchange runs
+            # under the other's MFMAs: the engine's rate at the per-GPU shape of configs[4]'s 4-GPU strong-scaling leg, exact engine beside it
+            x8 = synth_input(8192, T, dev, seed=99)
+            at8 = {}
+            for vname in ("bf16x3", "mfma2"):
+                model.kernel_variant = vname
+                ms8 = []
+                for i in range(1 + 3):
+                    model.initialize_hidden()
+                    model.warm_start()
+                    model.hidden = model.hidden.expand(1, 8192, 64).contiguous()
+                    ev0.record(); y8 = model.forward(x8); ev1.record(); torch.cuda.synchronize()
+                    if i:
+                        ms8.append(ev0.elapsed_time(ev1))
+                    del y8
+                at8[vname] = float(np.mean(ms8))
+            extra["bf16x3"]["at_8192_streams"] = {"kernel_ms": at8["bf16x3"], "samples_per_s_kernel": 8192.0 * T / (at8["bf16x3"] * 1e-3),
+                                                  "exact_fp32_kernel_ms": at8["mfma2"], "speedup_vs_exact_fp32_kernel": at8["mfma2"] / at8["bf16x3"]}
+            del x8
+            torch.cuda.empty_cache()
         model.kernel_variant = a.variant
         # the loss dict that follows the path in code/test-model.py:250-254 (never part of `value` beyond the ESR
         # sums the timed step already contains): ESR, DCPreESR and MultiSTFT over the whole batch, f16x3 output

@@ -967,8 +967,9 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         //      compiler form's, so the two forms agree bit for bit (tests/test_gpu_round6.py).
         //      Registers: the strings name single elements of tuples, which asm operands cannot express, so everything they
         //      touch lives in FIXED registers, declared to hipcc as physical-register operands / clobbers:
-        //        v[100:103] acc r -> r     v[104:107] acc n     v[108:111] acc z       v[112:115] n gate    v[116:119] h - n
-        //        v[120:123] z sigmoid      v[124:127] h (fp32)  v[128:129] hi pieces   v[130:133] mid, lo   v[134:141] scratch
+        //        v[100:103] acc r -> r     v[104:107] acc n     v[108:111] acc z       v[124:127] h (fp32)  v[128:129] hi pieces
+        //        v[130:141] scratch: mid / lo pieces and the split's temporaries in the first statement, the head partial in the
+        //        second, n gate (130:133), z sigmoid (134:137) and h - n (138:141) in the last
         //        v[142:165] B operands (hi, mid, lo x 2 K halves)    v[166:169] seed of the r accumulator (W_ir x + b)
         //        v[170:173] / v[210:213] seed of the z accumulator and v[174:177] / v[206:209] gi_n, by step parity (the
         //        values of step t+1 are formed before step t has used its own)    v[178:205] W_ih, biases, head weights
@@ -1079,29 +1080,29 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         // n + z (h - n) into the h registers, the hi pieces of h_t and their publication -- every wave's next step waits for it
 #define NTM3_S4(O_WH, SZC, GIC, GI0, GI1, GI2, GI3)                                                                                      \
         asm volatile(MF3("v[108:111]", "%[z00]", "v[142:145]", SZC) "v_rcp_f32 v103, v103\n\t"                                      \
-                     MF3("v[108:111]", "%[z10]", "v[146:149]", "v[108:111]") FMA("v112", "v100", "v104", GI0) FMA("v113", "v101", "v105", GI1) \
-                     MF3("v[108:111]", "%[z01]", "v[142:145]", "v[108:111]") FMA("v114", "v102", "v106", GI2) FMA("v115", "v103", "v107", GI3) \
-                     MF3("v[108:111]", "%[z11]", "v[146:149]", "v[108:111]") "v_exp_f32 v112, v112\n\t"                            \
-                     MF3("v[108:111]", "%[z02]", "v[142:145]", "v[108:111]") "v_exp_f32 v113, v113\n\t"                            \
-                     MF3("v[108:111]", "%[z12]", "v[146:149]", "v[108:111]") "v_exp_f32 v114, v114\n\t"                            \
-                     MF3("v[108:111]", "%[z00]", "v[150:153]", "v[108:111]") "v_exp_f32 v115, v115\n\t"                            \
-                     MF3("v[108:111]", "%[z10]", "v[154:157]", "v[108:111]") "v_add_f32 v112, 1.0, v112\n\tv_add_f32 v113, 1.0, v113\n\t" \
-                     MF3("v[108:111]", "%[z01]", "v[150:153]", "v[108:111]") "v_add_f32 v114, 1.0, v114\n\tv_add_f32 v115, 1.0, v115\n\t" \
-                     MF3("v[108:111]", "%[z11]", "v[154:157]", "v[108:111]") "v_rcp_f32 v112, v112\n\t"                            \
-                     MF3("v[108:111]", "%[z02]", "v[150:153]", "v[108:111]") "v_rcp_f32 v113, v113\n\t"                            \
-                     MF3("v[108:111]", "%[z12]", "v[154:157]", "v[108:111]") "v_rcp_f32 v114, v114\n\t"                            \
-                     MF3("v[108:111]", "%[z00]", "v[158:161]", "v[108:111]") "v_rcp_f32 v115, v115\n\t"                            \
-                     MF3("v[108:111]", "%[z10]", "v[162:165]", "v[108:111]") FMA("v112", "v112", "-2.0", "1.0") FMA("v113", "v113", "-2.0", "1.0") \
-                     MF3("v[108:111]", "%[z01]", "v[158:161]", "v[108:111]") FMA("v114", "v114", "-2.0", "1.0") FMA("v115", "v115", "-2.0", "1.0") \
+                     MF3("v[108:111]", "%[z10]", "v[146:149]", "v[108:111]") FMA("v130", "v100", "v104", GI0) FMA("v131", "v101", "v105", GI1) \
+                     MF3("v[108:111]", "%[z01]", "v[142:145]", "v[108:111]") FMA("v132", "v102", "v106", GI2) FMA("v133", "v103", "v107", GI3) \
+                     MF3("v[108:111]", "%[z11]", "v[146:149]", "v[108:111]") "v_exp_f32 v130, v130\n\t"                            \
+                     MF3("v[108:111]", "%[z02]", "v[142:145]", "v[108:111]") "v_exp_f32 v131, v131\n\t"                            \
+                     MF3("v[108:111]", "%[z12]", "v[146:149]", "v[108:111]") "v_exp_f32 v132, v132\n\t"                            \
+                     MF3("v[108:111]", "%[z00]", "v[150:153]", "v[108:111]") "v_exp_f32 v133, v133\n\t"                            \
+                     MF3("v[108:111]", "%[z10]", "v[154:157]", "v[108:111]") "v_add_f32 v130, 1.0, v130\n\tv_add_f32 v131, 1.0, v131\n\t" \
+                     MF3("v[108:111]", "%[z01]", "v[150:153]", "v[108:111]") "v_add_f32 v132, 1.0, v132\n\tv_add_f32 v133, 1.0, v133\n\t" \
+                     MF3("v[108:111]", "%[z11]", "v[154:157]", "v[108:111]") "v_rcp_f32 v130, v130\n\t"                            \
+                     MF3("v[108:111]", "%[z02]", "v[150:153]", "v[108:111]") "v_rcp_f32 v131, v131\n\t"                            \
+                     MF3("v[108:111]", "%[z12]", "v[154:157]", "v[108:111]") "v_rcp_f32 v132, v132\n\t"                            \
+                     MF3("v[108:111]", "%[z00]", "v[158:161]", "v[108:111]") "v_rcp_f32 v133, v133\n\t"                            \
+                     MF3("v[108:111]", "%[z10]", "v[162:165]", "v[108:111]") FMA("v130", "v130", "-2.0", "1.0") FMA("v131", "v131", "-2.0", "1.0") \
+                     MF3("v[108:111]", "%[z01]", "v[158:161]", "v[108:111]") FMA("v132", "v132", "-2.0", "1.0") FMA("v133", "v133", "-2.0", "1.0") \
                      MF3("v[108:111]", "%[z11]", "v[162:165]", "v[108:111]")                                                       \
-                     "v_sub_f32 v116, v124, v112\n\tv_sub_f32 v117, v125, v113\n\tv_sub_f32 v118, v126, v114\n\tv_sub_f32 v119, v127, v115\n\t" \
+                     "v_sub_f32 v138, v124, v130\n\tv_sub_f32 v139, v125, v131\n\tv_sub_f32 v140, v126, v132\n\tv_sub_f32 v141, v127, v133\n\t" \
                      "s_nop 1\n\t"                                                                                                \
-                     "v_exp_f32 v120, v108\n\tv_exp_f32 v121, v109\n\tv_exp_f32 v122, v110\n\tv_exp_f32 v123, v111\n\t"            \
-                     "v_pk_add_f32 v[120:121], v[120:121], 1.0 op_sel_hi:[1,0]\n\t"                                                \
-                     "v_pk_add_f32 v[122:123], v[122:123], 1.0 op_sel_hi:[1,0]\n\t"                                                \
-                     "v_rcp_f32 v120, v120\n\tv_rcp_f32 v121, v121\n\tv_rcp_f32 v122, v122\n\tv_rcp_f32 v123, v123\n\t"            \
-                     "v_pk_fma_f32 v[124:125], v[120:121], v[116:117], v[112:113]\n\t"                                             \
-                     "v_pk_fma_f32 v[126:127], v[122:123], v[118:119], v[114:115]\n\t"                                             \
+                     "v_exp_f32 v134, v108\n\tv_exp_f32 v135, v109\n\tv_exp_f32 v136, v110\n\tv_exp_f32 v137, v111\n\t"            \
+                     "v_pk_add_f32 v[134:135], v[134:135], 1.0 op_sel_hi:[1,0]\n\t"                                                \
+                     "v_pk_add_f32 v[136:137], v[136:137], 1.0 op_sel_hi:[1,0]\n\t"                                                \
+                     "v_rcp_f32 v134, v134\n\tv_rcp_f32 v135, v135\n\tv_rcp_f32 v136, v136\n\tv_rcp_f32 v137, v137\n\t"            \
+                     "v_pk_fma_f32 v[124:125], v[134:135], v[138:139], v[130:131]\n\t"                                             \
+                     "v_pk_fma_f32 v[126:127], v[136:137], v[140:141], v[132:133]\n\t"                                             \
                      "v_cvt_pk_bf16_f32 v128, v124, v125\n\tv_cvt_pk_bf16_f32 v129, v126, v127\n\t"                                \
                      "ds_write_b64 %[wr], v[128:129] offset:" O_WH                                                                \
                      : "+{v[124:127]}"(h4), "=&{v[128:129]}"(p0v), "=&{v[108:111]}"(acc3[2]), "+{v[100:103]}"(acc3[0])              \
@@ -1110,7 +1111,7 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
                        "{v[150:153]}"(B3[2]), "{v[154:157]}"(B3[3]), "{v[158:161]}"(B3[4]), "{v[162:165]}"(B3[5]),                 \
                        [z00] "v"(A3[2][0][0]), [z10] "v"(A3[2][1][0]), [z01] "v"(A3[2][0][1]), [z11] "v"(A3[2][1][1]),             \
                        [z02] "v"(A3[2][0][2]), [z12] "v"(A3[2][1][2])                                                             \
-                     : "memory", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123")
+                     : "memory", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141")
         if constexpr (cur == 0) NTM3_S4("6144", "v[170:173]", "v[174:177]", "v174", "v175", "v176", "v177");
         else NTM3_S4("0", "v[210:213]", "v[206:209]", "v206", "v207", "v208", "v209");
 #undef NTM3_S4

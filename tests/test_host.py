@@ -287,6 +287,7 @@ def test_recorded_bench_line_follows_the_contract():
     assert abs(b3["roofline_executed"]["frac"] - 196608.0 * 4096 * 65536 / (b3["kernel_ms"] * 1e-3) / 2.5e15) < 1e-9
     assert abs(b3["roofline_algorithmic"]["frac"] - 25088.0 * 4096 * 65536 / (b3["kernel_ms"] * 1e-3) / 157.3e12) < 1e-9
     assert b3["speedup_vs_exact_fp32_kernel"] > 1.3 and b3["stream0_vs_reference_max_abs"] < 1e-5
+    assert b3["at_8192_streams"]["speedup_vs_exact_fp32_kernel"] > 1.5        # two groups per CU: one's exchange under the other's MFMAs
     assert c["build"]["hip"] and c["build"]["runtime_hip"] and len(c["build"]["library_sha256"]) == 16
     assert d["build"]["library_sha256"].startswith(c["build"]["library_sha256"])
     assert d["unit"] == "samples/s" and d["higher_is_better"] is True and d["vs_baseline"] is None and d["data"] == "synthetic"

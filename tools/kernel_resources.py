@@ -32,7 +32,7 @@ PINNED_VGPRS = {
     (0, 16, 1, 1, 0): 234, (0, 4, 1, 1, 0): 228,
     (0, 16, 0, 1, 1): 264, (0, 4, 0, 1, 1): 220,          # ESR + DCP: 256 VGPRs + 8 AGPRs (AGPR spills, no scratch)
     (0, 16, 1, 1, 1): 251, (0, 4, 1, 1, 1): 243,          # FUSE + ESR + DCP
-    (2, 16, 0, 0, 0): 263, (2, 4, 0, 0, 0): 263,          # bf16x3 engine (round 6; opt-in): 256 VGPRs + 7 AGPRs outside the loop
+    (2, 16, 0, 0, 0): 250, (2, 4, 0, 0, 0): 250,          # bf16x3 engine (round 6; opt-in): <= 256, so that two groups share a CU from 8192 streams up
 }
 MFMA2_DYNAMIC_LDS = {16: 151680, 4: 53376}      # csrc/gru_mfma2.hip m2::smem_floats(YPN) * 4
 MFMA2_DYNAMIC_LDS_BF16X3 = {16: 153728, 4: 55424}      # ... m2::smem_floats(YPN, 2) * 4: the exchange buffer holds three pieces
