@@ -947,9 +947,10 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
     const f32x4 wo4 = {wo[0][0], wo[0][1], wo[1][0], wo[1][1]};
     f32x4 acc3[3];
     bf16x8 B3[6];
+    float x3_next = xb[j * XS + 1];          // x of step 1 (tile 0 is staged; a position beyond T holds 0)
     const unsigned rd_addr = (unsigned)(uintptr_t)(lds_cptr)h3rd, wr_addr = (unsigned)(uintptr_t)(lds_cptr)h3wr;
     const unsigned yp_addr = (unsigned)(uintptr_t)(lds_cptr)yp_lane;
-    (void)gi4; (void)wir4; (void)br4; (void)wiz4; (void)bz4; (void)win4; (void)bin4; (void)wo4;
+    (void)x3_next; (void)gi4; (void)wir4; (void)br4; (void)wiz4; (void)bz4; (void)win4; (void)bin4; (void)wo4;
     (void)h4; (void)p0v; (void)seed_r; (void)seed_z; (void)bhn4; (void)acc3; (void)B3; (void)rd_addr; (void)wr_addr; (void)yp_addr;
 #endif
     auto step_b = [&](const int64_t t, auto cur_c, auto hk_c) {
@@ -973,8 +974,9 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         //        v[142:165] B operands (hi, mid, lo x 2 K halves)    v[166:169] seed of the r accumulator (W_ir x + b)
         //        v[170:173] / v[210:213] seed of the z accumulator and v[174:177] / v[206:209] gi_n, by step parity (the
         //        values of step t+1 are formed before step t has used its own)    v[178:205] W_ih, biases, head weights
-        //      Waits inside the strings are by hand: lgkmcnt(0) only (LDS returns in order, so an LDS op hipcc has in flight
-        //      is harmless); MFMA result -> vector read >= 28 cycles after the MFMA's issue; transcendental result -> next
+        //      Waits inside the strings are by hand: lgkmcnt(0), and one lgkmcnt(2) in the first statement -- behind its own full
+        //      wait, where the only four LDS ops in flight are that statement's two hi reads and two mid / lo writes (LDS returns
+        //      in order, so an LDS op hipcc has in flight elsewhere is harmless); MFMA result -> vector read >= 28 cycles after the MFMA's issue; transcendental result -> next
         //      vector use one state later; permlane swaps as in park_head.
         constexpr int cur = decltype(cur_c)::value;   // == t & 1: which exchange buffer holds h_{t-1}
         static_assert(PRESCALE, "the asm form of the bf16x3 step folds the log2(e) factors into the weights");
@@ -982,8 +984,9 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
         const int64_t tile = t >> 6;
         NTM2_STAMP(0)
         housekeeping(t, ph, tile, hk_c);
-        // (hipcc-issued, retired by the first statement's wait) x of step t+1; the slot the head partial of y_{t-1} parks in
-        const float xn = xb[(((t + 1) >> 6) & 1) * SG * XS + j * XS + (int)((t + 1) & 63)];
+        // x of step t+1 was fetched during step t-1 (behind the r chain: an LDS read issued here would sit between the hi-piece
+        // write and barrier 1 and hold the barrier up for its own latency); the slot the head partial of y_{t-1} parks in
+        const float xn = x3_next;
         const unsigned ya = yp_addr + 4u * (unsigned)((int)(((t - 1) >> 6) & 1) * YPN * YP_Q + (int)((t - 1) & 63));
         NTM2_STAMP(1)
 #define MF3(D, A, B, C) "v_mfma_f32_16x16x32_bf16 " D ", " A ", " B ", " C "\n\t"
@@ -1001,9 +1004,9 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
                      "v_pk_add_f32 v[138:139], v[138:139], v[134:135]" NEG "v_pk_add_f32 v[140:141], v[140:141], v[136:137]" NEG   \
                      "v_cvt_pk_bf16_f32 v132, v138, v139\n\tv_cvt_pk_bf16_f32 v133, v140, v141\n\t"                                \
                      "ds_write_b64 %[wr], v[130:131] offset:" O_WM "\n\tds_write_b64 %[wr], v[132:133] offset:" O_WL "\n\t"      \
-                     "s_waitcnt lgkmcnt(0)\n\t"                                                                                   \
+                     "s_waitcnt lgkmcnt(2)\n\t"                                                                                   \
                      MF3("v[100:103]", "%[r00]", "v[142:145]", "v[166:169]")                                                       \
-                     "s_barrier\n\t"                                                                                              \
+                     "s_waitcnt lgkmcnt(0)\n\ts_barrier\n\t"                                                                     \
                      "ds_read_b128 v[150:153], %[rd] offset:" O_M0 "\n\tds_read_b128 v[154:157], %[rd] offset:" O_M1 "\n\t"      \
                      "ds_read_b128 v[158:161], %[rd] offset:" O_L0 "\n\tds_read_b128 v[162:165], %[rd] offset:" O_L1 "\n\t"      \
                      MF3("v[100:103]", "%[r10]", "v[146:149]", "v[100:103]")                                                       \
@@ -1059,6 +1062,8 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
 #undef NTM3_PARK16
 #undef NTM3_PARK4
         NTM2_STAMP(3)
+        // (hipcc-issued; its tile was staged at phase 34 of the previous tile at the latest) x of step t+2, for the next step's input terms
+        x3_next = xb[(((t + 2) >> 6) & 1) * SG * XS + j * XS + (int)((t + 2) & 63)];
         // n chain, mid and lo pieces; from its second gap on the r sigmoid, in place: 4 x v_exp, 4 x v_add, 3 of the 4 x v_rcp
         asm volatile(MF3("v[104:107]", "%[n00]", "v[150:153]", "v[104:107]")
                      MF3("v[104:107]", "%[n10]", "v[154:157]", "v[104:107]") "v_exp_f32 v100, v100\n\t"
