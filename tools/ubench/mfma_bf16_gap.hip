@@ -40,6 +40,8 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cyc, in
 #define F11 "v_and_b32 %8, 0xffff0000, %6\n\tv_lshlrev_b32 %9, 16, %6\n\t"
 #define F12 "v_add_f32 %6, 1.0, %6\n\tv_add_f32 %8, 1.0, %8\n\tv_add_f32 %9, 1.0, %9\n\tv_add_f32 %10, 1.0, %10\n\t"
 #define F13 "v_rcp_f32 %6, %6\n\tv_exp_f32 %8, %8\n\t"
+#define F14 "v_cvt_pk_bf16_f32 %8, %6, %9\n\tv_cvt_pk_bf16_f32 %10, %9, %6\n\t"
+#define F15 "v_sub_f32 %8, %6, %9\n\tv_sub_f32 %10, %9, %6\n\t"
 #define BODY(F)                                                                                                          \
         if (NACC == 0) asm volatile(X16(F) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(A), "v"(B), "v"(e), "v"(p), "v"(e2), "v"(e3), "v"(e4));       \
         else if (NACC == 1) asm volatile(X16(M("%0") F) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(A), "v"(B), "v"(e), "v"(p), "v"(e2), "v"(e3), "v"(e4));       \
@@ -48,7 +50,7 @@ __global__ __launch_bounds__(256) void k(float *out, unsigned long long *cyc, in
         if (FILL == 0) { BODY(F0) } else if (FILL == 1) { BODY(F1) } else if (FILL == 2) { BODY(F2) }
         else if (FILL == 3) { BODY(F3) } else if (FILL == 4) { BODY(F4) } else if (FILL == 5) { BODY(F5) } else if (FILL == 6) { BODY(F6) }
         else if (FILL == 7) { BODY(F7) } else if (FILL == 8) { BODY(F8) } else if (FILL == 9) { BODY(F9) } else if (FILL == 10) { BODY(F10) }
-        else if (FILL == 11) { BODY(F11) } else if (FILL == 12) { BODY(F12) } else { BODY(F13) }
+        else if (FILL == 11) { BODY(F11) } else if (FILL == 12) { BODY(F12) } else if (FILL == 13) { BODY(F13) } else if (FILL == 14) { BODY(F14) } else { BODY(F15) }
     }
     STAMP(t1);
     out[threadIdx.x] = a0[0] + a1[1] + a2[2] + a3[3] + e + p[0] + e2 + e3 + e4;
@@ -70,6 +72,7 @@ int main()
     run<2, 0>("nothing"); run<2, 1>("v_exp_f32"); run<2, 2>("2 x v_pk_add_f32"); run<2, 3>("v_exp_f32 + v_pk_add_f32"); run<2, 4>("s_nop 0"); run<2, 5>("s_nop 1");
     run<1, 6>("1 x v_pk_add_f32"); run<1, 7>("2 x v_add_f32"); run<1, 8>("2 x v_fma_f32"); run<1, 9>("v_exp_f32 + v_add_f32");
     run<0, 6>("1 x v_pk_add_f32, NO MFMA"); run<0, 7>("2 x v_add_f32, NO MFMA"); run<0, 1>("v_exp_f32, NO MFMA"); run<0, 10>("v_cvt_pk_bf16_f32, NO MFMA");
+    run<1, 14>("2 x v_cvt_pk_bf16_f32"); run<1, 15>("2 x v_sub_f32 (independent)"); run<2, 7>("2 x v_add_f32"); run<2, 11>("v_and_b32 + v_lshlrev_b32"); run<2, 14>("2 x v_cvt_pk_bf16_f32"); run<2, 15>("2 x v_sub_f32 (independent)");
     run<1, 10>("v_cvt_pk_bf16_f32"); run<1, 11>("v_and_b32 + v_lshlrev_b32"); run<1, 12>("4 x v_add_f32"); run<1, 13>("v_rcp_f32 + v_exp_f32");
     return 0;
 }
