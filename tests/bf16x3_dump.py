@@ -25,5 +25,22 @@ for B, T in ((1040, 4096), (4112, 300), (8200, 129), (1040, 1)):
     if y1 is not None:
         out[f"y1_{B}_{T}"] = y1.cpu().numpy()
     out[f"h_{B}_{T}"] = m.hidden.cpu().numpy()
+# larger batches as bit-pattern checksums (sum and xor of the int32 views, per stream): every sample of every stream counts,
+# the files stay small -- the headline shape's own generator, one group per CU (4096) and two per CU (8200: YPN = 4)
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+for B, T in ((4096, 16384), (8200, 4096)):
+    x = bench.synth_input(B, T, torch.device("cuda", 0), seed=1234)
+    y = m.predict(x)
+    bits = y.view(torch.int32)[:, 0].to(torch.int64)
+    out[f"sum_{B}_{T}"] = bits.sum(dim=1).cpu().numpy()
+    folded = bits
+    while folded.shape[1] > 1:
+        half = folded.shape[1] // 2
+        folded = torch.bitwise_xor(folded[:, :half], folded[:, half:2 * half]) if folded.shape[1] % 2 == 0 else torch.cat(
+            [torch.bitwise_xor(folded[:, :half], folded[:, half:2 * half]), folded[:, 2 * half:]], dim=1)
+    out[f"xor_{B}_{T}"] = folded[:, 0].cpu().numpy()
+    out[f"hsum_{B}_{T}"] = m.hidden.view(torch.int32).to(torch.int64).sum(dim=2).cpu().numpy()
+    del x, y, bits, folded
 np.savez(sys.argv[1], **out)
 print("lib", os.path.basename(ntm_amd._lib.LIB_PATH), "ok")

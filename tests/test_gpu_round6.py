@@ -61,7 +61,8 @@ def test_bf16x3_against_the_oracle_ragged_shapes_and_carried_state(ntm, B, T):
 @pytest.mark.gpu
 def test_bf16x3_hand_scheduled_form_is_bit_identical_to_the_compiler_scheduled_form(tmp_path):
     """The asm statements of step_b fix registers, order and wait states by hand; the same arithmetic compiled without them
-    (NTM3_ASM = 0, libntm_bf16x3c.so) must give the same BITS -- outputs and carried state, ragged lengths, both LDS layouts.
+    (NTM3_ASM = 0, libntm_bf16x3c.so) must give the same BITS -- outputs and carried state, ragged lengths, both LDS layouts, and
+    bit-pattern checksums of every stream of 4096 x 16 384 and 8200 x 4096 batches of the headline's own input generator.
     A stale register, a missing wait state or a wrong operand in the strings shows here as a difference, not as noise."""
     libdir = os.path.join(ROOT, "neural-tape-modeling_amd")
     outs = {}
@@ -74,7 +75,7 @@ def test_bf16x3_hand_scheduled_form_is_bit_identical_to_the_compiler_scheduled_f
         assert r.returncode == 0 and f"lib {lib} ok" in r.stdout, r.stderr[-2000:]
         outs[lib] = np.load(dst)
     a, b = outs["libntm.so"], outs["libntm_bf16x3c.so"]
-    assert sorted(a.files) == sorted(b.files) and len(a.files) >= 11
+    assert sorted(a.files) == sorted(b.files) and len(a.files) >= 17           # 11 arrays + 2 x 3 checksums of the large batches
     for k in a.files:
         assert a[k].shape == b[k].shape and np.isfinite(a[k]).all() and np.array_equal(a[k], b[k]), k
 
