@@ -815,7 +815,7 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch segments per GPU (N = 8: BASELINE configs[4]); strong: --total-batch segments over all GPUs")
     ap.add_argument("--total-batch", type=int, default=32768, help="segments of the whole job under --scaling strong")
-    ap.add_argument("--variant", default="auto", choices=["auto", "mfma2", "mfma4", "mfma", "valu", "f16x3", "bf16x3"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "mfma2", "mfma", "valu", "f16x3", "bf16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="full", choices=["full", "small"],
                     help="cpu_baseline: full = 16 x 8192 best of 3 + 64 x 8192 (about 10 s); small = 16 x 8192 once (tests)")
@@ -1193,7 +1193,7 @@ def main():
                 "frac": tflops / peak_tflops, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes": float(bytes_per_sample) * B * T,
                 "kernel": {"auto": "gru_mfma2_kernel", "mfma2": "gru_mfma2_kernel", "mfma": "gru_mfma_kernel",
-                           "valu": "gru_valu_kernel", "f16x3": "gru_mfma2_kernel<f16x3>", "mfma4": "gru_mfma4_kernel",
+                           "valu": "gru_valu_kernel", "f16x3": "gru_mfma2_kernel<f16x3>",
                            "bf16x3": "gru_mfma2_kernel<bf16x3>"}[a.variant]
                           + ("<ESR: forward + loss sums>" if fused_esr else ""),
                 "kernel_ms": 1e3 * kern_s, "flop_per_sample": flop_per_sample, "per": "GPU (rank 0's launch)",

@@ -50,10 +50,9 @@ extern "C" {
 #define NTM_GRU_MFMA 1  /* 16 streams / workgroup, 4 waves, v_mfma_f32_16x16x4_f32, h in LDS */
 #define NTM_GRU_VALU 2  /* 2 streams / wavefront, W_hh in VGPRs, h broadcast through LDS     */
 #define NTM_GRU_MFMA2 3 /* as MFMA, own-quarter-first step order: LDS exchange hidden by MFMAs */
-#define NTM_GRU_MFMA3 5 /* exact fp32 hybrid: MFMA waves + partner VALU waves on the same SIMDs       */
+#define NTM_GRU_MFMA3 5 /* retired in round 6 (a measured negative result; the number stays reserved)     */
 #define NTM_GRU_LAT 6   /* exact fp32, ONE stream per workgroup (K split over 4 waves): low latency, small B */
-#define NTM_GRU_MFMA4 7 /* exact fp32, ONE wavefront per 4 streams on v_mfma_f32_4x4x1_16B_f32: no barrier, no exchange
-                           between waves (h feeds the next step from the registers it was computed in, BLGP-routed) */
+#define NTM_GRU_MFMA4 7 /* retired in round 6 (a measured negative result; the number stays reserved)     */
 #define NTM_GRU_LAT_MAX_B 1024
 #define NTM_GRU_F16X3 4 /* OPT-IN: MFMA2 with W.h as three fp16 hi/lo products, fp32 accumulate  */
 #define NTM_GRU_BF16X3 8 /* OPT-IN: MFMA2 with W and h each split into THREE bf16 pieces (24 bits: the fp32 operands exactly) and

@@ -21,9 +21,9 @@ const char *ntm_lab_last_error(void);
  * Same contract as ntm_gru_forward_ex (code/model.py:81-82), for variant in
  *   NTM_GRU_MFMA   first matrix-pipe kernel (natural K order, LDS exchange exposed)
  *   NTM_GRU_VALU   one wavefront per two streams on v_fma_f32 (north_star's first idea)
- *   NTM_GRU_MFMA3  MFMA waves + partner VALU waves on the same SIMDs (negative result)
- *   NTM_GRU_MFMA4  one wavefront per 4 streams on v_mfma_f32_4x4x1_16B_f32, no barrier (negative result: the chip
- *                  clocks down under 4x4x1 MFMAs)
+ * (NTM_GRU_MFMA3 -- MFMA waves + partner VALU waves on the same SIMDs -- and NTM_GRU_MFMA4 -- one wavefront per 4 streams on
+ *  v_mfma_f32_4x4x1_16B_f32 -- were measured negative results of rounds 2-5 and are retired: docs/DESIGN_measurement_log_r1_r5.md
+ *  4 K1d / K1f, sources in the history up to round 5.)
  * H must be 64.
  */
 int ntm_lab_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,

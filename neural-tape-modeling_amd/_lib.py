@@ -13,7 +13,7 @@ LAB_PATH = os.environ.get("NTM_LAB_PATH") or os.path.join(_HERE, "libntm_lab.so"
 
 NTM_GRU_AUTO, NTM_GRU_MFMA, NTM_GRU_VALU, NTM_GRU_MFMA2, NTM_GRU_F16X3, NTM_GRU_MFMA3, NTM_GRU_LAT, NTM_GRU_MFMA4, NTM_GRU_BF16X3 = 0, 1, 2, 3, 4, 5, 6, 7, 8
 VARIANTS = {"auto": NTM_GRU_AUTO, "mfma": NTM_GRU_MFMA, "valu": NTM_GRU_VALU, "mfma2": NTM_GRU_MFMA2,
-            "f16x3": NTM_GRU_F16X3, "mfma3": NTM_GRU_MFMA3, "lat": NTM_GRU_LAT, "mfma4": NTM_GRU_MFMA4, "bf16x3": NTM_GRU_BF16X3}
+            "f16x3": NTM_GRU_F16X3, "lat": NTM_GRU_LAT, "bf16x3": NTM_GRU_BF16X3}
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -63,7 +63,7 @@ _LAB_SIGNATURES = {
     "ntm_lab_tcn_stamps": (_int, [_vp]),
     "ntm_lab_tcn_trace": (_int, [_vp]),
 }
-LAB_VARIANTS = ("mfma", "valu", "mfma3", "mfma4")
+LAB_VARIANTS = ("mfma", "valu")
 
 _lib = None
 _lab = None

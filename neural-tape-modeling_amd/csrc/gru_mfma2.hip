@@ -198,9 +198,6 @@ __device__ __forceinline__ f32x4 pack_hl(const f16x4 hi, const f16x4 lo)
 //   the next tile -- no LDS traffic (the step barrier's hand-counted lgkmcnt stays valid), ~70 vector instructions per
 //   thread and tile.  fp32 filter (scan order instead of the streaming kernel's; both agree with the sequential
 //   recursion of the oracle to ~1e-6 relative in the sums), fp64 sums.
-#ifndef NTM_TANH_FORM
-#define NTM_TANH_FORM 0
-#endif
 #ifndef NTM3_ASM
 #define NTM3_ASM 1        // ENGINE 2: the hand-scheduled MFMA / gate block (0: the compiler-scheduled form, same arithmetic, for the A/B)
 #endif
@@ -848,21 +845,13 @@ __global__ __launch_bounds__(256, 1) void gru_mfma2_kernel(GruArgs a)
             const f32x2 z = {__builtin_amdgcn_rcpf(ez[0]), __builtin_amdgcn_rcpf(ez[1])};
             f32x2 pn = __builtin_elementwise_fma(r, an, gi[p]);        // (2 log2e) (gi_n + r gh_n) if PRESCALE
             if (!PRESCALE) pn *= 2.0f * LOG2E;
-#if NTM_TANH_FORM == 1
-            // EXPERIMENT (never in libntm.so: `make exp` builds libntm_tanh1.so for tools/attic/tanh_form_probe.py): tanh as
-            // sign(p) (1 - t) rcp(1 + t), t = 2^-|p| <= 1 -- no cancellation for small |n| (tools/ubench/gate_ulp.hip: abs.
-            // error 1.35e-8 instead of 4.6e-8 there), no overflow; costs one packed op and two v_bfi_b32 per pair more.
-            const f32x2 tn = {__builtin_amdgcn_exp2f(-__builtin_fabsf(pn[0])), __builtin_amdgcn_exp2f(-__builtin_fabsf(pn[1]))};
-            const f32x2 dn = one + tn;
-            const f32x2 rn = {__builtin_amdgcn_rcpf(dn[0]), __builtin_amdgcn_rcpf(dn[1])};
-            const f32x2 na = (one - tn) * rn;
-            const f32x2 n = {__builtin_copysignf(na[0], pn[0]), __builtin_copysignf(na[1], pn[1])};
-#else
             f32x2 en = {__builtin_amdgcn_exp2f(pn[0]), __builtin_amdgcn_exp2f(pn[1])};
             en += one;
             const f32x2 rn = {__builtin_amdgcn_rcpf(en[0]), __builtin_amdgcn_rcpf(en[1])};
-            const f32x2 n = __builtin_elementwise_fma((f32x2){-2.0f, -2.0f}, rn, one);   // tanh
-#endif
+            // tanh as 1 - 2 / (1 + 2^p).  The form sign(p) (1 - t) rcp(1 + t), t = 2^-|p|, has no cancellation for small |n| but cost
+            // 1.8 % of the step and left the full-batch worst error at 6.0e-6 (6.8e-6 here): measured in round 6, not adopted
+            // (profiles/r06_b_full_batch_parity.jsonl)
+            const f32x2 n = __builtin_elementwise_fma((f32x2){-2.0f, -2.0f}, rn, one);
             hn[p] = __builtin_elementwise_fma(z, hold[p] - n, n);                         // n + z (h - n)
         }
         asm volatile("" : "+v"(hn[0]), "+v"(hn[1]));

@@ -38,9 +38,7 @@ int ntm_lab_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih,
     switch (variant) {
         case NTM_GRU_MFMA: e = ntm::launch_gru_mfma(a, (hipStream_t)stream); break;
         case NTM_GRU_VALU: e = ntm::launch_gru_valu(a, (hipStream_t)stream); break;
-        case NTM_GRU_MFMA3: e = ntm::launch_gru_mfma3(a, (hipStream_t)stream); break;
-        case NTM_GRU_MFMA4: e = ntm::launch_gru_mfma4(a, (hipStream_t)stream); break;
-        default: return fail(NTM_EINVAL, "ntm_lab_gru_forward: not a laboratory variant (NTM_GRU_MFMA, _VALU, _MFMA3, _MFMA4)");
+        default: return fail(NTM_EINVAL, "ntm_lab_gru_forward: not a laboratory variant (NTM_GRU_MFMA, _VALU)");
     }
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_lab_gru_forward");
 }

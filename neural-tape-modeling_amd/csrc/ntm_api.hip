@@ -104,9 +104,11 @@ int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, 
         case NTM_GRU_LAT: e = ntm::launch_gru_lat(a, (hipStream_t)stream); break;
         case NTM_GRU_F16X3: a.engine = 1; e = ntm::launch_gru_mfma2(a, (hipStream_t)stream); break;
         case NTM_GRU_BF16X3: a.engine = 2; e = ntm::launch_gru_mfma2(a, (hipStream_t)stream); break;
-        case NTM_GRU_MFMA: case NTM_GRU_VALU: case NTM_GRU_MFMA3: case NTM_GRU_MFMA4:
+        case NTM_GRU_MFMA: case NTM_GRU_VALU:
             return fail(NTM_EINVAL, "ntm_gru_forward: laboratory kernel variant -- those live in libntm_lab.so "
                                     "(ntm_lab_gru_forward, include/ntm_lab.h), not in the product library");
+        case NTM_GRU_MFMA3: case NTM_GRU_MFMA4:
+            return fail(NTM_EINVAL, "ntm_gru_forward: kernel variant retired in round 6 (a measured negative result)");
         default: return fail(NTM_EINVAL, "ntm_gru_forward: unknown kernel variant");
     }
     return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_gru_forward");

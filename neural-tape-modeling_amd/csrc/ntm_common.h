@@ -68,9 +68,7 @@ hipError_t launch_gru_mfma(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_valu(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_mfma2_fused(const GruArgs &a, hipStream_t stream);   // GRU + head + delay line in one launch
-hipError_t launch_gru_mfma3(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_lat(const GruArgs &a, hipStream_t stream);
-hipError_t launch_gru_mfma4(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_small(const GruArgs &a, int H, hipStream_t stream);   // any H in [1, 1024] but 64
 hipError_t launch_debug_transpose(const float *in, float *out, hipStream_t stream);
 }  // namespace ntm

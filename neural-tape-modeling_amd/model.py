@@ -80,7 +80,7 @@ class _GRUHead(torch.nn.Module):
     """GRU(1,H) + Linear(H,1[,bias]) state and launch logic shared by RNN and DiffDelRNN."""
 
     # product kernels (libntm.so): "auto" | "mfma2" | "lat" | "f16x3" / "bf16x3" (opt-in split engines);  laboratory kernels for A/B and as
-    # independent implementations in the tests (libntm_lab.so): "mfma" | "valu" | "mfma3" | "mfma4"  (NTM_GRU_*)
+    # independent implementations in the tests (libntm_lab.so): "mfma" | "valu"  (NTM_GRU_*)
     kernel_variant = "auto"
     warm_cache = False         # True: keep the warm-start state per parameter version (module docstring; harness.build_model turns it on)
 

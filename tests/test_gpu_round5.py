@@ -467,7 +467,7 @@ def _record_full(name, **row):
     import json
     path = os.path.join(ROOT, "gpurun_out", "r06_full_batch_parity.jsonl")
     os.makedirs(os.path.dirname(path), exist_ok=True)
-    lib = os.path.basename(os.environ.get("NTM_LIB_PATH") or "libntm.so")       # (libntm_tanh1.so: the tanh-form A/B of round 6)
+    lib = os.path.basename(os.environ.get("NTM_LIB_PATH") or "libntm.so")       # (an A/B build reached through NTM_LIB_PATH is named in the record)
     with open(path, "a") as f:
         f.write(json.dumps(dict(config=name, library=lib, **row)) + "\n")
 
@@ -492,7 +492,8 @@ def test_full_size_cfg2_every_stream_against_the_oracle(ntm):
     reference by goldens g1 / g2 / g6 / g19 / g20 -- about 20 s on the box's cores).  Output and carried state of every
     stream inside 1e-5.  Round 6: the oracle's fp64 mode (pinned to torch's double modules by g20) separates the device's
     rounding from the fp32 oracle's own: per stream |hip - f64| and |oracle32 - f64|; the distributions go into
-    gpurun_out/r06_full_batch_parity.jsonl (run again with NTM_LIB_PATH=.../libntm_tanh1.so for the tanh-form A/B)."""
+    gpurun_out/r06_full_batch_parity.jsonl (round 6 ran it once more with an A/B build of the other tanh form through
+    NTM_LIB_PATH: profiles/r06_b_full_batch_parity.jsonl; not adopted, the build is retired)."""
     import sys
     import time
     from helpers import oracle_weights
