@@ -82,6 +82,49 @@ def test_gru_random_shapes_hidden_sizes_and_chunkings(ntm, H, B, T, seed, cuts):
     assert torch.equal(y1, y2) and torch.equal(h1, m.hidden)
 
 
+@settings(max_examples=40, **SET)
+@given(B=st.integers(1, 70), T=st.integers(1, 400), seed=st.integers(0, 2**31 - 1), cuts=st.lists(st.integers(1, 399), max_size=2),
+       scale=st.sampled_from([0.01, 0.125, 1.0, 3.0]), tiny=st.booleans())
+def test_bf16x3_engine_random_weights_magnitudes_and_chunkings(ntm, B, T, seed, cuts, scale, tiny):
+    """The operand-exact split engine (NTM_GRU_BF16X3, round 6) on RANDOM H = 64 weights whose magnitudes span five decades
+    (`scale` x the PyTorch init range; `tiny`: a third of W_hh multiplied by 1e-4, so that the second and third bf16 pieces of
+    some operands fall ten binades below the first) and random states: within 1e-5 of the oracle, carried state included, the
+    exact engine within 2e-6 / 5e-6 beside it, chunked == one-shot bit for bit.  Any batch size: the variant bypasses the
+    dispatch, a group of fewer than 16 streams included."""
+    H = 64
+    rng = np.random.default_rng(seed)
+    k = scale / np.sqrt(H)
+    whh = rng.uniform(-k, k, (3 * H, H))
+    if tiny:
+        whh[rng.random((3 * H, H)) < 1.0 / 3.0] *= 1e-4
+    sd = {"GRU.weight_ih_l0": rng.uniform(-k, k, (3 * H, 1)), "GRU.weight_hh_l0": whh,
+          "GRU.bias_ih_l0": rng.uniform(-k, k, 3 * H), "GRU.bias_hh_l0": rng.uniform(-k, k, 3 * H),
+          "output.weight": rng.uniform(-k, k, (1, H)), "output.bias": rng.uniform(-k, k, 1)}
+    sd = {n: v.astype(np.float32) for n, v in sd.items()}
+    x = rng.uniform(-0.9, 0.9, (B, T)).astype(np.float32)
+    h0 = (rng.uniform(-0.9, 0.9, (B, H)) * rng.choice([1.0, 1e-3, 1e-6], (B, 1))).astype(np.float32)
+    w = oracle.Weights.from_state_dict(sd)
+    yo, ho = oracle.gru_forward(w, x, h0.copy())
+    outs = {}
+    for variant in ("bf16x3", "mfma2"):
+        m = ntm.RNN(1, H, 1)
+        m.load_state_dict({n: torch.from_numpy(v) for n, v in sd.items()})
+        m = m.to("cuda").eval()
+        m.kernel_variant = variant
+        m.hidden = dev(h0).view(1, B, H).clone()
+        y1 = m(dev(x).unsqueeze(1))
+        h1 = m.hidden.clone()
+        assert np.abs(y1[:, 0].cpu().numpy() - yo).max() < TOL and np.abs(h1[0].cpu().numpy() - ho).max() < TOL, variant
+        outs[variant] = (y1, h1)
+        if variant == "bf16x3":
+            m.hidden = dev(h0).view(1, B, H).clone()
+            edges = [0] + sorted({c for c in cuts if c < T}) + [T]
+            y2 = torch.cat([m(dev(x[:, a:b]).unsqueeze(1)) for a, b in zip(edges, edges[1:])], dim=2)
+            assert torch.equal(y1, y2) and torch.equal(h1, m.hidden)
+    assert (outs["bf16x3"][0] - outs["mfma2"][0]).abs().max().item() < 2e-6 * max(1.0, scale)
+    assert (outs["bf16x3"][1] - outs["mfma2"][1]).abs().max().item() < 5e-6
+
+
 # ----------------------------------------------------------------------------- K4: TCN, both tilings
 DIL = st.one_of(st.integers(1, 40), st.integers(512, 700))
 
