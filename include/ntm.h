@@ -32,7 +32,7 @@ extern "C" {
 #define NTM_EHIP (-2)    /* HIP runtime error (launch failed, no device)               */
 #define NTM_EDELAY (-3)  /* reserved for host-side delay-range checks                  */
 
-#define NTM_ABI_VERSION 9 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag.  3: the TCN scratch is padded (ntm_tcn_scratch_floats grew), dilation / length limits.  4: ntm_diffdel_gru_forward is ONE fused launch where the matrix-pipe kernel runs (+ ntm_diffdel_gru_forward_ex).  5: ntm_gru_forward_esr, ntm_diffdel_gru_forward_esr.  6: ntm_tcn_forward works through the batch in stream chunks, ntm_tcn_scratch_floats is bounded (<= 2.0e9 floats + padding for any B), ntm_tcn_chunk_streams; DiffDelGRU warm-up calls always take the two-pass form.  7: ntm_loss_scalars (+ include/ntm_rccl.h, libntm_rccl.so).  8: any hidden size in [1, NTM_MAX_HIDDEN]; ntm_gru_forward_losses / ntm_diffdel_gru_forward_losses (ESR + DCPreESR sums in the recurrent launch).  9: NTM_GRU_BF16X3 */
+#define NTM_ABI_VERSION 9 /* 2: hidden sizes 8/16/32/64; the delay line is one pass, no scratch, sticky error flag.  3: the TCN scratch is padded (ntm_tcn_scratch_floats grew), dilation / length limits.  4: ntm_diffdel_gru_forward is ONE fused launch where the matrix-pipe kernel runs (+ ntm_diffdel_gru_forward_ex).  5: ntm_gru_forward_esr, ntm_diffdel_gru_forward_esr.  6: ntm_tcn_forward works through the batch in stream chunks, ntm_tcn_scratch_floats is bounded (<= 2.0e9 floats + padding for any B), ntm_tcn_chunk_streams; DiffDelGRU warm-up calls always take the two-pass form.  7: ntm_loss_scalars (+ include/ntm_rccl.h, libntm_rccl.so).  8: any hidden size in [1, NTM_MAX_HIDDEN]; ntm_gru_forward_losses / ntm_diffdel_gru_forward_losses (ESR + DCPreESR sums in the recurrent launch).  9: NTM_GRU_BF16X3, ntm_gru_forward_io (any input_size / output_size) */
 
 #define NTM_HIDDEN 64 /* hidden size of every shipped checkpoint (HS[64]): matrix-pipe and low-latency kernels.
                          Every other H in [1, NTM_MAX_HIDDEN] (the reference's `--HIDDEN_SIZE` is a free integer,
@@ -82,6 +82,20 @@ int ntm_gru_forward(const float *w_ih, const float *w_hh, const float *b_ih, con
                     const float *w_o, const float *b_o, int H, const float *x, float *y,
                     int64_t B, int64_t T, int64_t x_stride_b, int64_t y_stride_b, float *h_state,
                     void *stream);
+
+/*
+ * The same reference call for ANY input_size / output_size: self.GRU = nn.GRU(input_size, hidden_size, batch_first=True),
+ * self.output = nn.Linear(hidden_size, output_size) (code/model.py:22,44-45), forward code/model.py:67-88.  The reference moves
+ * between (B, C, T) and (B, T, C) with `reshape` (:77, :87) -- a reinterpretation of the row, not a transpose -- so per stream the
+ * input row of I T floats IS the [T][I] matrix the GRU reads and the output row of O T floats IS the [T][O] matrix the head
+ * writes: x [B] rows of T*I floats (x_stride_b >= T*I), y [B] rows of T*O floats.  w_ih [3H, I], w_o [O, H], b_o [O] or NULL;
+ * h_state [B, H] in/out or NULL (zeros).  H, I, O in [1, 1024].  No caller of the reference uses sizes other than 1
+ * (code/test-model.py:124-125): a plain, correct kernel (a workgroup per stream, weights from L2), not a fast one; pinned by
+ * golden g22 from the reference's own forward().  The skip connection (y += x, output_size == input_size) is the caller's.
+ */
+int ntm_gru_forward_io(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,
+                       const float *w_o, const float *b_o, int H, int I, int O, const float *x, float *y,
+                       int64_t B, int64_t T, int64_t x_stride_b, int64_t y_stride_b, float *h_state, void *stream);
 
 /* Same, with an explicit kernel variant (NTM_GRU_*); used by bench.py / tests to A/B kernels. */
 int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh,

@@ -297,7 +297,85 @@ __global__ __launch_bounds__(256) void gru_wide_kernel(GruArgs a)
         for (int i = tid; i < H; i += 256) a.h_state[b * H + i] = hs[T & 1][i];
 }
 
+// General input_size / output_size (code/model.py:22,44-45: nn.GRU(input_size, H) + nn.Linear(H, output_size); no caller of the
+// reference uses sizes other than 1, so this is protocol completeness, plain and correct like gru_wide_kernel<false>, nothing more).
+// The reference reinterprets (B, C, T) as (B, T, C) with `reshape` (code/model.py:77,87): per stream the input row IS the [T][I]
+// matrix the GRU reads and the output row IS the [T][O] matrix the head writes.  A 4-wave workgroup per stream; per step the
+// rows of W_hh go round the waves (coalesced loads, a DPP sum per row), the gates read W_ih . x_t from L2 (I products per gate,
+// summed in i = 0..I-1 order), the O head rows go round the waves again; three barriers per step.
+__global__ __launch_bounds__(256) void gru_io_kernel(GruArgs a, int I, int O)
+{
+#pragma clang fp contract(off)
+    constexpr int HMAX = 1024;
+    __shared__ float hs[2][HMAX];
+    __shared__ float gh[3 * HMAX];
+    __shared__ float xs[HMAX];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = a.H;
+    const int64_t b = blockIdx.x, T = a.T;
+    const float *xrow = a.x + b * a.xs;
+    float *yrow = a.y + b * a.ys;
+    for (int i = tid; i < HMAX; i += 256) {
+        hs[0][i] = (i < H && a.h_state) ? a.h_state[b * H + i] : 0.0f;
+        hs[1][i] = 0.0f;
+    }
+    auto wave_sum = [&](float v) {          // sum over the wave's 64 lanes, valid in lane 63
+        v = dpp_add<0x111, 0xf>(v); v = dpp_add<0x112, 0xf>(v); v = dpp_add<0x114, 0xf>(v); v = dpp_add<0x118, 0xf>(v);
+        v = dpp_add<0x142, 0xa>(v); v = dpp_add<0x143, 0xc>(v);
+        return v;
+    };
+    __syncthreads();
+    for (int64_t t = 0; t < T; ++t) {
+        const int cur = (int)(t & 1);
+        for (int i = tid; i < I; i += 256) xs[i] = xrow[t * I + i];
+        for (int r = wv; r < 3 * H; r += 4) {
+            const float *row = a.w_hh + (size_t)r * H;
+            float acc = 0.0f;
+            for (int c = lane; c < H; c += 64) acc = __builtin_fmaf(row[c], hs[cur][c], acc);
+            acc = wave_sum(acc);
+            if (lane == 63) gh[r] = acc;
+        }
+        __syncthreads();
+        for (int u = tid; u < H; u += 256) {
+            float gi[3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const float *wr = a.w_ih + (size_t)(g * H + u) * I;
+                float acc = 0.0f;
+                for (int i = 0; i < I; ++i) acc = __builtin_fmaf(wr[i], xs[i], acc);
+                gi[g] = acc + a.b_ih[g * H + u];
+            }
+            const float r = sigmoid_f32(gi[0] + (gh[u] + a.b_hh[u]));
+            const float z = sigmoid_f32(gi[1] + (gh[H + u] + a.b_hh[H + u]));
+            const float n = tanh_f32(__builtin_fmaf(r, gh[2 * H + u] + a.b_hh[2 * H + u], gi[2]));
+            hs[cur ^ 1][u] = __builtin_fmaf(z, hs[cur][u] - n, n);
+        }
+        __syncthreads();
+        for (int o = wv; o < O; o += 4) {
+            const float *row = a.w_o + (size_t)o * H;
+            float acc = 0.0f;
+            for (int c = lane; c < H; c += 64) acc = __builtin_fmaf(row[c], hs[cur ^ 1][c], acc);
+            acc = wave_sum(acc);
+            if (lane == 63) yrow[t * O + o] = a.b_o ? acc + a.b_o[o] : acc;
+        }
+        __syncthreads();                    // xs, gh and hs[cur] are rewritten by the next step
+    }
+    if (a.h_state)
+        for (int i = tid; i < H; i += 256) a.h_state[b * H + i] = hs[T & 1][i];
+}
+
 }   // namespace
+
+hipError_t launch_gru_io(const GruArgs &a0, int H, int I, int O, hipStream_t stream)
+{
+    if (a0.B == 0 || a0.T == 0) return hipSuccess;
+    if (H < 1 || H > 1024 || I < 1 || I > 1024 || O < 1 || O > 1024 || a0.B > 0x7fffffff) return hipErrorInvalidValue;
+    GruArgs a = a0;
+    a.H = H;
+    hipLaunchKernelGGL(gru_io_kernel, dim3((unsigned)a.B), dim3(256), 0, stream, a, I, O);
+    return hipGetLastError();
+}
 
 // Any hidden size but 64 (ntm_api.hip routes H = 64 to the matrix-pipe / low-latency kernels).
 hipError_t launch_gru_small(const GruArgs &a0, int H, hipStream_t stream)

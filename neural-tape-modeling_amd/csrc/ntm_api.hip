@@ -56,6 +56,23 @@ int ntm_abi_version(void) { return NTM_ABI_VERSION; }
 
 const char *ntm_last_error(void) { return g_err.c_str(); }
 
+int ntm_gru_forward_io(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *w_o,
+                       const float *b_o, int H, int I, int O, const float *x, float *y, int64_t B, int64_t T,
+                       int64_t x_stride_b, int64_t y_stride_b, float *h_state, void *stream)
+{
+    if (H < 1 || H > NTM_MAX_HIDDEN) return fail(NTM_EINVAL, "ntm_gru_forward_io: hidden size must lie in [1, 1024]");
+    if (I < 1 || I > 1024 || O < 1 || O > 1024) return fail(NTM_EINVAL, "ntm_gru_forward_io: input_size and output_size must lie in [1, 1024]");
+    if (B < 0 || T < 0) return fail(NTM_EINVAL, "ntm_gru_forward_io: negative B or T");
+    if (B == 0 || T == 0) return NTM_OK;
+    if (!w_ih || !w_hh || !b_ih || !b_hh || !w_o || !x || !y) return fail(NTM_EINVAL, "ntm_gru_forward_io: null pointer");
+    if (x_stride_b < T * I || y_stride_b < T * O) return fail(NTM_EINVAL, "ntm_gru_forward_io: row stride below T * size");
+    if (B > 0x7fffffff) return fail(NTM_EINVAL, "ntm_gru_forward_io: at most 2^31 - 1 streams per call");
+    if (x == y) return fail(NTM_EINVAL, "ntm_gru_forward_io: y must not alias x");
+    ntm::GruArgs a{w_ih, w_hh, b_ih, b_hh, w_o, b_o, x, y, h_state, B, T, x_stride_b, y_stride_b, nullptr, 0, 0};
+    hipError_t e = ntm::launch_gru_io(a, H, I, O, (hipStream_t)stream);
+    return e == hipSuccess ? NTM_OK : hip_fail(e, "ntm_gru_forward_io");
+}
+
 int ntm_gru_forward_ex(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *w_o,
                        const float *b_o, int H, const float *x, float *y, int64_t B, int64_t T, int64_t x_stride_b,
                        int64_t y_stride_b, float *h_state, int variant, void *stream)

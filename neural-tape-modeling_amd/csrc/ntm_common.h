@@ -70,5 +70,6 @@ hipError_t launch_gru_mfma2(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_mfma2_fused(const GruArgs &a, hipStream_t stream);   // GRU + head + delay line in one launch
 hipError_t launch_gru_lat(const GruArgs &a, hipStream_t stream);
 hipError_t launch_gru_small(const GruArgs &a, int H, hipStream_t stream);   // any H in [1, 1024] but 64
+hipError_t launch_gru_io(const GruArgs &a, int H, int I, int O, hipStream_t stream);   // any input_size / output_size (gru_small.hip)
 hipError_t launch_debug_transpose(const float *in, float *out, hipStream_t stream);
 }  // namespace ntm

@@ -95,10 +95,14 @@ class _GRUHead(torch.nn.Module):
     def invalidate_warm_cache(self):
         self._warm = None
 
-    def _init_net(self, input_size, hidden_size, output_size, skip, head_bias):
-        if input_size != 1 or output_size != 1:
-            raise ValueError("only input_size = output_size = 1 is built (every reference checkpoint and "
-                             "caller uses 1: code/test-model.py:123-124)")
+    def _init_net(self, input_size, hidden_size, output_size, skip, head_bias, general_io=False):
+        for what, v in (("input_size", input_size), ("output_size", output_size)):
+            if not isinstance(v, (int, np.integer)) or not 1 <= v <= 1024:
+                raise ValueError(f"{what} {v!r}: an integer in [1, 1024]")
+        if (input_size != 1 or output_size != 1) and not general_io:
+            raise ValueError("DiffDelRNN is built for input_size = output_size = 1 (its delay line is single-channel; every "
+                             "reference checkpoint and caller uses 1: code/test-model.py:124-125); RNN takes any sizes")
+        input_size, output_size = int(input_size), int(output_size)
         # any hidden size the reference can be trained with (`--HIDDEN_SIZE` is a free integer, code/train.py:50): 64 (every
         # shipped checkpoint) has the matrix-pipe / low-latency kernels, 8 / 16 / 32 their own, every other size up to
         # 1024 the padded or wide kernels of csrc/gru_small.hip
@@ -197,17 +201,50 @@ class RNN(_GRUHead):
 
     def __init__(self, input_size=1, hidden_size=8, output_size=1, skip=False):
         super().__init__()
-        self._init_net(input_size, hidden_size, output_size, skip, head_bias=True)
+        self._init_net(input_size, hidden_size, output_size, skip, head_bias=True, general_io=True)
         self.initialize_hidden()
 
     def initialize_hidden(self):
         """Initialize GRU hidden state to zeros (code/model.py:50-52)."""
         self.hidden = None
 
+    @property
+    def _general_io(self):
+        return self.input_size != 1 or self.output_size != 1
+
+    def _forward_io(self, x):
+        """forward() for input_size / output_size other than 1 (code/model.py:22,44-45,67-88; ntm_gru_forward_io): the reference
+        reinterprets (B, C, T) as (B, T, C) with `reshape`, so the contiguous input row IS the [T][C] matrix the GRU reads and the
+        [T][O] matrix the head writes IS the output row.  A plain kernel -- no caller of the reference uses these sizes."""
+        if x.dim() != 3:
+            raise RuntimeError(f"RNN.forward: expected (N_BATCHES, N_CHANNELS, N_SAMPLES), got {tuple(x.shape)}")
+        B, C, T = x.shape
+        I, O, H = self.input_size, self.output_size, self.hidden_size
+        if C != I:          # torch.nn.GRU's own check on the reshaped input
+            raise RuntimeError(f"input.size(-1) must be equal to input_size. Expected {I}, got {C}")
+        _require_hip(x, "RNN.forward")
+        _require_hip(self.GRU.weight_hh_l0, "model parameters (call .to('cuda'))")
+        if self.skip and not (O == I or I == 1):    # y (B, T, O) += skip (B, T, C): only these shapes broadcast in place
+            raise RuntimeError(f"The size of tensor a ({O}) must match the size of tensor b ({I}) at non-singleton dimension 2")
+        xr = (x.float() if x.dtype != torch.float32 else x).contiguous().view(B, C * T)
+        h = self._hidden_for(B, x.device)
+        y = torch.empty(B, O * T, device=x.device, dtype=torch.float32)
+        g, o = self.GRU, self.output
+        rc = _lib.lib().ntm_gru_forward_io(ptr(g.weight_ih_l0), ptr(g.weight_hh_l0), ptr(g.bias_ih_l0), ptr(g.bias_hh_l0), ptr(o.weight),
+                                           ptr(o.bias), H, I, O, ptr(xr), ptr(y), B, T, C * T, O * T, ptr(h), _lib.current_stream())
+        _lib.check(rc, "ntm_gru_forward_io")
+        self.hidden = h
+        if self.skip:       # on the (B, T, .) views the reference adds in
+            yv = y.view(B, T, O)
+            yv += xr.view(B, T, I)
+        return y.view(B, O, T)
+
     def warm_start(self):
         """Process 1024 samples of silence, B=1 (code/model.py:58-65).  From a fresh state (hidden None) the result
         depends on the parameters only and is kept per parameter version (module docstring)."""
         START_LEN = 2**10
+        if self.input_size != 1:            # the reference feeds zeros((1, 1, 1024)) whatever input_size is: torch.nn.GRU raises
+            raise RuntimeError(f"input.size(-1) must be equal to input_size. Expected {self.input_size}, got 1")
         fresh = self.hidden is None and self.warm_cache
         if fresh:
             key = self._warm_key()
@@ -226,7 +263,10 @@ class RNN(_GRUHead):
 
     @torch.no_grad()
     def forward(self, x):
-        """x (N_BATCHES, 1, N_SAMPLES) -> y same shape; stateful (code/model.py:67-88)."""
+        """x (N_BATCHES, N_CHANNELS = input_size, N_SAMPLES) -> y (N_BATCHES, output_size, N_SAMPLES); stateful
+        (code/model.py:67-88).  input_size = output_size = 1 (every shipped checkpoint and caller) runs the kernels of DESIGN.md 0."""
+        if self._general_io:
+            return self._forward_io(x)
         xbt = _as_bt(x, "RNN.forward")
         y = self._gru(xbt)
         if self.skip:

@@ -45,6 +45,7 @@ def lib():
         _LIB.ntmo_gru_forward.argtypes = [_f32p] * 6 + [ctypes.c_int, _f32p, _f32p,
                                                         ctypes.c_int64, ctypes.c_int64, _f32p]
         _LIB.ntmo_gru_forward_mt.argtypes = _LIB.ntmo_gru_forward.argtypes + [ctypes.c_int]
+        _LIB.ntmo_gru_forward_io.argtypes = [_f32p] * 6 + [ctypes.c_int] * 3 + [_f32p, _f32p, ctypes.c_int64, ctypes.c_int64, _f32p]
         _LIB.ntmo_gru_forward_f64_mt.argtypes = [_f32p] * 6 + [ctypes.c_int, _f32p, _f64p, ctypes.c_int64, ctypes.c_int64, _f64p, ctypes.c_int]
         _LIB.ntmo_delay_forward_f64.argtypes = [_f64p, _f32p, _f64p, ctypes.c_int64, ctypes.c_int64, _f64p, ctypes.c_int, ctypes.c_int]
         _LIB.ntmo_delay_forward.argtypes = [_f32p, _f32p, _f32p, ctypes.c_int64, ctypes.c_int64,
@@ -145,6 +146,25 @@ def diffdel_predict(w, x, d, max_delay, threads=1):
     z = np.zeros((1, 1024), np.float32)
     _, _, h1, b1 = diffdel_forward(w, z, z, None, np.zeros((1, D), np.float32))
     return diffdel_forward(w, x, d, np.repeat(h1, B, 0), np.repeat(b1, B, 0), threads=threads)
+
+
+def gru_forward_io(sd, x, h=None):
+    """RNN.forward for ANY input_size / output_size (code/model.py:67-88), the reference's reshape semantics included:
+    x (B, C, T) -> y (B, O, T) where both are reinterpretations (reshape, not transpose) of the [T][C] / [T][O] matrices the
+    GRU and the head see.  `sd`: the reference's state_dict as numpy arrays.  -> (y, h_out [B,H])."""
+    w_ih = _c(sd["GRU.weight_ih_l0"])
+    w_hh = _c(sd["GRU.weight_hh_l0"])
+    w_o = _c(sd["output.weight"])
+    H, I, O = w_hh.shape[1], w_ih.shape[1], w_o.shape[0]
+    b_o = _c(sd["output.bias"]) if sd.get("output.bias") is not None else None
+    x = _c(x)
+    B, C, T = x.shape
+    assert C == I, f"input has {C} channels, the GRU takes {I}"
+    h = np.zeros((B, H), np.float32) if h is None else _c(h).copy()
+    y = np.empty((B, T * O), np.float32)
+    assert lib().ntmo_gru_forward_io(_p(w_ih), _p(w_hh), _p(_c(sd["GRU.bias_ih_l0"])), _p(_c(sd["GRU.bias_hh_l0"])), _p(w_o), _p(b_o),
+                                     H, I, O, _p(x.reshape(B, T * I)), _p(y), B, T, _p(h)) == 0
+    return y.reshape(B, O, T), h
 
 
 def _pd(a):

@@ -110,6 +110,58 @@ int ntmo_gru_forward_mt(const float *w_ih, const float *w_hh, const float *b_ih,
 }
 
 /*
+ * General input_size / output_size (code/model.py:22,44-45: nn.GRU(input_size, H, batch_first=True) + nn.Linear(H, output_size)).
+ * The reference moves between (B, C, T) and (B, T, C) with `reshape` (code/model.py:77,87) -- a reinterpretation of the row, not a
+ * transpose -- so per stream the input row of C T floats IS the [T][I] matrix the GRU reads, and the [T][O] matrix the head writes IS
+ * the output row: x [B, T*I], y [B, T*O].  w_ih [3H, I], w_o [O, H], b_o [O] or NULL.  Same operation order as gru_stream
+ * (the input products of a gate are summed in i = 0..I-1 order on top of b_ih).  No caller of the reference uses sizes other
+ * than 1 (code/test-model.py:124-125, code/train.py:87-88); pinned by golden g22 from the reference's own forward().
+ */
+int ntmo_gru_forward_io(const float *w_ih, const float *w_hh, const float *b_ih, const float *b_hh, const float *w_o,
+                        const float *b_o, int H, int I, int O, const float *x, float *y, int64_t B, int64_t T, float *h_state)
+{
+    if (H <= 0 || I <= 0 || O <= 0 || B < 0 || T < 0) return -1;
+    const int G = 3 * H;
+    float *wt = transpose_whh(w_hh, H);
+    float *gh = (float *)malloc(sizeof(float) * (size_t)G);
+    float *gi = (float *)malloc(sizeof(float) * (size_t)G);
+    float *hn = (float *)malloc(sizeof(float) * (size_t)H);
+    for (int64_t b = 0; b < B; ++b) {
+        float *h = h_state + b * H;
+        const float *xb = x + b * T * I;
+        float *yb = y + b * T * O;
+        for (int64_t t = 0; t < T; ++t) {
+            for (int g = 0; g < G; ++g) gh[g] = 0.0f;
+            for (int k = 0; k < H; ++k) {
+                const float hk = h[k];
+                const float *col = wt + (size_t)k * G;
+                for (int g = 0; g < G; ++g) gh[g] += col[g] * hk;
+            }
+            for (int g = 0; g < G; ++g) {
+                gh[g] += b_hh[g];
+                float acc = 0.0f;
+                for (int i = 0; i < I; ++i) acc += w_ih[(size_t)g * I + i] * xb[t * I + i];
+                gi[g] = acc + b_ih[g];
+            }
+            for (int j = 0; j < H; ++j) {
+                const float r = sigmoidf_(gi[j] + gh[j]);
+                const float z = sigmoidf_(gi[H + j] + gh[H + j]);
+                const float n = tanhf(gi[2 * H + j] + r * gh[2 * H + j]);
+                hn[j] = (h[j] - n) * z + n;
+            }
+            memcpy(h, hn, sizeof(float) * (size_t)H);
+            for (int o = 0; o < O; ++o) {
+                float yo = 0.0f;
+                for (int j = 0; j < H; ++j) yo += w_o[(size_t)o * H + j] * h[j];
+                yb[t * O + o] = b_o ? yo + b_o[o] : yo;
+            }
+        }
+    }
+    free(wt); free(gh); free(gi); free(hn);
+    return 0;
+}
+
+/*
  * fp64 mode of the same restatement (code/model.py:81-82 evaluated in double: fp32 parameters and input, `double` state,
  * accumulators, exp / tanh): the yardstick that separates the device's rounding from the fp32 oracle's own -- per stream
  * |hip - f64| against |oracle32 - f64| (tests/test_gpu_round6.py).  Not a parity target: the reference computes in fp32

@@ -148,6 +148,18 @@ def test_state_dict_protocol():
     for bad in (0, -3, 1025, 2.5):
         with pytest.raises(ValueError):
             ntm_amd.RNN(1, bad, 1)                             # outside [1, NTM_MAX_HIDDEN] / not an integer
+    # round 6: any input_size / output_size (code/model.py:22,44-45), parameter shapes as torch.nn.GRU / Linear make them
+    r = ntm_amd.RNN(3, 24, 5)
+    ref_g, ref_o = torch.nn.GRU(3, 24, batch_first=True), torch.nn.Linear(24, 5)
+    assert {k: tuple(v.shape) for k, v in r.GRU.state_dict().items()} == {k: tuple(v.shape) for k, v in ref_g.state_dict().items()}
+    assert {k: tuple(v.shape) for k, v in r.output.state_dict().items()} == {k: tuple(v.shape) for k, v in ref_o.state_dict().items()}
+    with pytest.raises(RuntimeError, match="Expected 3, got 1"):      # the reference's warm_start feeds zeros((1, 1, 1024))
+        r.warm_start()
+    for bad in (0, 1025, 1.5):
+        with pytest.raises(ValueError):
+            ntm_amd.RNN(bad, 8, 1)
+    with pytest.raises(ValueError, match="DiffDelRNN"):
+        ntm_amd.DiffDelRNN(2, 8, 1)                            # its delay line is single-channel
 
 
 def test_no_cpu_fallback():

@@ -449,3 +449,23 @@ def test_oracle_fp64_mode_against_the_reference_modules_in_double_g20():
     y, pre, h, buf = oracle.diffdel_predict_f64(oracle_weights(str(g["dd_toy_weights"])), x, g["dd_toy_d"][None], int(g["dd_toy_max_delay"]))
     assert np.abs(pre[0] - g["dd_toy_pre64"].astype(np.float64)).max() < 4e-8 and np.abs(y[0] - g["dd_toy_y64"].astype(np.float64)).max() < 4e-8
     assert np.abs(buf[0] - g["dd_toy_buffer"]).max() < 1e-5 and np.abs(h[0] - g["dd_toy_hidden"]).max() < 1e-5
+
+
+def test_g22_general_input_and_output_sizes():
+    """RNN.forward of the REFERENCE for input_size / output_size other than 1 (golden g22, tools/make_goldens_io.py): nn.GRU(I, H) +
+    nn.Linear(H, O) with the reference's reshape semantics (code/model.py:77,87: the (B, C, T) row is reinterpreted as [T][C], not
+    transposed), state carried over two calls, one case with the skip connection.  The oracle within 2e-6 of the reference."""
+    g = load("g22_io_sizes.npz")
+    for name in [str(c) for c in g["cases"]]:
+        I, H, O, skip, cut = (int(v) for v in g[f"{name}__meta"])
+        sd = {k.split("__", 1)[1]: g[k] for k in g.files if k.startswith(name + "__GRU.") or k.startswith(name + "__output.")}
+        x = g[f"{name}__x"]
+        B, _, T = x.shape
+        y1, h = oracle.gru_forward_io(sd, x[:, :, :cut])
+        y2, h = oracle.gru_forward_io(sd, x[:, :, cut:], h)
+        if skip:            # y += skip on the (B, T, C) view == the (B, C, T) rows reinterpreted: elementwise on the flat rows
+            y1 = y1 + np.ascontiguousarray(x[:, :, :cut]).reshape(y1.shape)
+            y2 = y2 + np.ascontiguousarray(x[:, :, cut:]).reshape(y2.shape)
+        y = np.concatenate([y1, y2], axis=2)
+        assert y.shape == g[f"{name}__y"].shape == (B, O, T)
+        assert np.abs(y - g[f"{name}__y"]).max() < 2e-6 and np.abs(h - g[f"{name}__h"]).max() < 2e-6, name
