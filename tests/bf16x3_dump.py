@@ -42,5 +42,17 @@ for B, T in ((4096, 16384), (8200, 4096)):
     out[f"xor_{B}_{T}"] = folded[:, 0].cpu().numpy()
     out[f"hsum_{B}_{T}"] = m.hidden.view(torch.int32).to(torch.int64).sum(dim=2).cpu().numpy()
     del x, y, bits, folded
+# optional soak (NTM_DUMP_SOAK=n, not part of the suite's default): n seeded random shapes and states, checksums only
+n_soak = int(os.environ.get("NTM_DUMP_SOAK", "0"))
+rng = np.random.default_rng(2026)
+for k in range(n_soak):
+    B = int(rng.choice([1, 7, 16, 17, 100, 1040, 2500, 4096, 4112, 5000, 8200]))
+    T = int(rng.integers(1, 700))
+    g = torch.Generator(device="cuda").manual_seed(10_000 + k)
+    x = torch.rand(B, 1, T, generator=g, device="cuda") * 1.6 - 0.8
+    m.hidden = (torch.rand(1, B, 64, generator=g, device="cuda") * 1.8 - 0.9) * float(rng.choice([1.0, 1e-3]))
+    y = m(x)
+    out[f"soak{k}_{B}_{T}"] = np.concatenate([y.view(torch.int32).to(torch.int64).sum(dim=2)[:, 0].cpu().numpy(),
+                                              m.hidden.view(torch.int32).to(torch.int64).sum(dim=2)[0].cpu().numpy()])
 np.savez(sys.argv[1], **out)
 print("lib", os.path.basename(ntm_amd._lib.LIB_PATH), "ok")
